@@ -1,0 +1,25 @@
+/*
+ * cghip_debug.h -- introspection entry points of libcghip.so used by the test-suite only. They have no
+ * counterpart in the reference (which has no tests) and no production caller.
+ */
+#ifndef CGHIP_DEBUG_H
+#define CGHIP_DEBUG_H
+
+#include "cghip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Runs the host planner (image_kernel::draw host math + register binding) and copies out the kernel
+ * program; needs no GPU. kops_out receives records of cghip_debug_kop_size() bytes each. */
+int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces, const cghip_draw* draws,
+                     int ndraws, void* kops_out, int capacity, int* nops, int* full);
+int cghip_debug_kop_size(void);
+/* A plane descriptor with no device memory behind it, for planner tests. Release with cghip_plane_release. */
+int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_plane** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

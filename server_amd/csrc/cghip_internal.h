@@ -1,0 +1,106 @@
+/* cghip_internal.h -- private declarations shared by the libcghip.so translation units. */
+#ifndef CGHIP_INTERNAL_H
+#define CGHIP_INTERNAL_H
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cghip.h"
+#include "cghip_kops.h"
+
+namespace cghip {
+
+void set_error(const std::string& msg);
+int  fail(int status, const std::string& msg);
+int  fail_hip(hipError_t e, const char* what);
+
+#define CGHIP_TRY_HIP(expr)                                                                                            \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return cghip::fail_hip(e__, #expr);                                                                        \
+    } while (0)
+
+/* size-keyed free lists, the HIP counterpart of ogl::device's texture / host-buffer pools
+ * (accelerator/ogl/util/device.cpp:66-67,194-233) */
+struct pool {
+    std::multimap<size_t, void*> free_;
+    size_t                       bytes_free = 0, bytes_total = 0, count_total = 0;
+};
+
+} // namespace cghip
+
+struct cghip_device {
+    int         gpu = 0;
+    std::string name;
+    hipStream_t upload_stream = nullptr; /* H2D of producer planes; shared by all producer threads */
+    std::mutex  mu;
+    cghip::pool device_pool; /* hipMalloc'd blocks: planes, frame outputs, op lists */
+    cghip::pool pinned_pool; /* hipHostMalloc'd blocks */
+    std::atomic<int64_t> planes_live{0}, tickets_live{0}, frames_rendered{0}, mixers{0};
+
+    int  dev_alloc(size_t bytes, void** out);
+    void dev_free(void* p, size_t bytes);
+    int  pinned_alloc(size_t bytes, void** out);
+    void pinned_free(void* p, size_t bytes);
+};
+
+struct cghip_hostbuf {
+    cghip_device* dev;
+    void*         ptr;
+    size_t        bytes;
+};
+
+struct cghip_plane {
+    cghip_device*    dev      = nullptr;
+    void*            dptr     = nullptr;
+    size_t           bytes    = 0;
+    int              width = 0, height = 0, channels = 0, bits = 0;
+    hipEvent_t       ready    = nullptr; /* recorded after the upload / peer copy */
+    std::atomic<int> refs{1};
+    bool             stub = false; /* planner tests: no device memory behind it */
+};
+
+struct cghip_mixer {
+    cghip_device* dev        = nullptr;
+    int           channel_id = 0;
+    hipStream_t   stream     = nullptr; /* compositor + readback of this channel */
+};
+
+struct cghip_ticket {
+    cghip_device*             dev   = nullptr;
+    hipStream_t               stream = nullptr;
+    void*                     d_out = nullptr;
+    size_t                    out_bytes = 0;
+    void*                     h_out = nullptr; /* pinned, when CGHIP_RENDER_READBACK */
+    void*                     d_ops = nullptr;
+    void*                     h_ops = nullptr; /* pinned staging of the op list */
+    size_t                    ops_bytes = 0;
+    hipEvent_t                ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    int                       launches = 0;
+    std::vector<cghip_plane*> planes; /* retained until the frame is done */
+};
+
+namespace cghip {
+
+struct frame_plan {
+    std::vector<KOp> ops;
+    bool             full = false; /* needs the RGBA1/RGBA2 register surfaces */
+    std::vector<cghip_plane*> planes; /* every plane referenced by an emitted op */
+};
+
+/* image_renderer / image_kernel host logic -> KOp list. Pure host code (no HIP calls). */
+int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces, const cghip_draw* draws,
+               int ndraws, frame_plan* out);
+
+} // namespace cghip
+
+extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
+                                             int field_mode, int full, hipStream_t stream);
+
+#endif

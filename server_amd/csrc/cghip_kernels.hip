@@ -1,0 +1,688 @@
+/*
+ * cghip_kernels.hip -- the fused gfx950 compositor: ONE launch per frame replaces every
+ * glDrawArrays of the reference renderer (accelerator/ogl/image/image_kernel.cpp:402) and the
+ * fragment shader they run (accelerator/ogl/image/shader.frag:523-542).
+ *
+ * Mapping (wave64): one wave owns 64*P consecutive pixels of ONE output row, a 256-thread workgroup owns
+ * 4 consecutive rows of the same column span, so source rows shared by vertically adjacent outputs
+ * (bilinear taps, 4:2:0 chroma) are served by the CU's L1. Every lane walks the frame's KOp list
+ * (wave-uniform, scalar loads) and keeps all render surfaces of the reference (target, layer, mix and
+ * key textures) in VGPRs; HBM traffic is source texels in, one BGRA pixel out.
+ *
+ * Numerics follow what the reference's shaders do under a GL implementation (goldens: Mesa llvmpipe):
+ *  - the store after EVERY draw rounds to UNORM8/16 (round-to-nearest-even of x*(2^n-1)), emulated in
+ *    registers between ops, because every reference draw lands in an RGBA8 texture;
+ *  - 8-bit textures are filtered with 8-bit weights and rounded integer lerps, 16-bit ones in fp32;
+ *  - coverage uses 24.8 fixed-point edge functions with the top-left rule (exact, in double).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cghip_kops.h"
+
+#include <type_traits>
+
+#define DEV __device__ __forceinline__
+
+/* compile-time loop: the per-pixel register arrays must never be indexed dynamically (that would put them
+ * in scratch memory) */
+template <int I, int N, class F>
+DEV void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct f4 {
+    float x, y, z, w;
+};
+struct f3 {
+    float x, y, z;
+};
+
+/* ------------------------------------------------------------------ UNORM store emulation */
+
+template <int BITS>
+struct Q {
+    static constexpr float scale   = BITS == 8 ? 255.0f / 256.0f : 65535.0f / 65536.0f;
+    static constexpr float magic   = BITS == 8 ? 32768.0f : 128.0f;
+    static constexpr float dequant = BITS == 8 ? 256.0f / 255.0f : 65536.0f / 65535.0f; /* == 2^n * fl(1/(2^n-1)) */
+    static constexpr float unit    = BITS == 8 ? 256.0f : 65536.0f;
+};
+
+/* float -> the float a later texture fetch of the stored UNORM would return: clamp, scale, add the
+ * magic constant (leaves exactly n fraction bits, round-to-nearest-even), subtract it again. */
+template <int BITS>
+DEV float quantize(float x)
+{
+    x       = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); /* NaN -> 0 like the clamp before a UNORM store */
+    float r = __fadd_rn(__fmul_rn(x, Q<BITS>::scale), Q<BITS>::magic);
+    float t = __fsub_rn(r, Q<BITS>::magic); /* = k / 2^n exactly */
+    return __fmul_rn(t, Q<BITS>::dequant);  /* = fl(k * fl(1/(2^n-1))) */
+}
+template <int BITS>
+DEV uint32_t to_code(float q)
+{ /* inverse of the dequant step: q = k*fl(1/(2^n-1)) -> k */
+    return (uint32_t)__builtin_rintf(q * (BITS == 8 ? 255.0f : 65535.0f));
+}
+
+/* ------------------------------------------------------------------ texel fetch + filtering */
+
+DEV int imin(int a, int b) { return a < b ? a : b; }
+DEV int imax(int a, int b) { return a > b ? a : b; }
+DEV int iclamp(int v, int lo, int hi) { return imin(imax(v, lo), hi); }
+
+/* 8-bit texel as a packed word in MEMORY channel order (byte k = k-th sample of the texel) */
+DEV uint32_t load8(const KPlane& p, int x, int y)
+{
+    const size_t   idx = (size_t)y * (size_t)p.w + (size_t)x;
+    const uint8_t* b   = (const uint8_t*)p.ptr;
+    switch (p.channels) {
+        case 1: return b[idx];
+        case 2: return ((const uint16_t*)p.ptr)[idx];
+        case 3: return (uint32_t)b[idx * 3] | ((uint32_t)b[idx * 3 + 1] << 8) | ((uint32_t)b[idx * 3 + 2] << 16);
+        default: return ((const uint32_t*)p.ptr)[idx];
+    }
+}
+
+/* a + ((w*(b-a) + 128) >> 8) on four packed bytes at once: (a*(256-w) + b*w + 128) >> 8 per byte */
+DEV uint32_t lerp8x4(uint32_t a, uint32_t b, uint32_t w)
+{
+    const uint32_t iw = 256u - w;
+    uint32_t       e  = ((a & 0x00FF00FFu) * iw + (b & 0x00FF00FFu) * w + 0x00800080u) >> 8;
+    uint32_t       o  = ((a >> 8) & 0x00FF00FFu) * iw + ((b >> 8) & 0x00FF00FFu) * w + 0x00800080u;
+    return (e & 0x00FF00FFu) | (o & 0xFF00FF00u);
+}
+
+/* memory-order samples -> GL texel (r,g,b,a): strides 3/4 were uploaded as GL_BGR/GL_BGRA
+ * (accelerator/ogl/util/texture.cpp:31-33) */
+DEV f4 gl_texel(int channels, float m0, float m1, float m2, float m3)
+{
+    switch (channels) {
+        case 1: return f4{m0, 0.0f, 0.0f, 1.0f};
+        case 2: return f4{m0, m1, 0.0f, 1.0f};
+        case 3: return f4{m2, m1, m0, 1.0f};
+        default: return f4{m2, m1, m0, m3};
+    }
+}
+
+/* GL_LINEAR + CLAMP_TO_EDGE fetch of an 8-bit plane at fixed-point texel coordinates (24.8, already
+ * shifted by half a texel). */
+DEV f4 sample8_fixed(const KPlane& p, int iu, int iv)
+{
+    int            x0 = iu >> 8, y0 = iv >> 8;
+    const uint32_t wx = (uint32_t)(iu & 0xff), wy = (uint32_t)(iv & 0xff);
+    const int      x1 = iclamp(x0 + 1, 0, p.w - 1), y1 = iclamp(y0 + 1, 0, p.h - 1);
+    x0                = iclamp(x0, 0, p.w - 1);
+    y0                = iclamp(y0, 0, p.h - 1);
+    uint32_t a        = load8(p, x0, y0);
+    if (wx != 0)
+        a = lerp8x4(a, load8(p, x1, y0), wx);
+    if (wy != 0) {
+        uint32_t b = load8(p, x0, y1);
+        if (wx != 0)
+            b = lerp8x4(b, load8(p, x1, y1), wx);
+        a = lerp8x4(a, b, wy);
+    }
+    const float sc = 1.0f / 255.0f;
+    return gl_texel(p.channels, (float)(a & 0xff) * sc, (float)((a >> 8) & 0xff) * sc, (float)((a >> 16) & 0xff) * sc,
+                    (float)(a >> 24) * sc);
+}
+
+DEV void load16(const KPlane& p, int x, int y, float m[4])
+{
+    const size_t    idx = ((size_t)y * (size_t)p.w + (size_t)x) * (size_t)p.channels;
+    const uint16_t* s   = (const uint16_t*)p.ptr;
+    const float     sc  = 1.0f / 65535.0f;
+    m[0] = m[1] = m[2] = m[3] = 0.0f;
+    switch (p.channels) {
+        case 1: m[0] = (float)s[idx] * sc; break;
+        case 2: {
+            uint32_t v = *(const uint32_t*)(s + idx);
+            m[0] = (float)(v & 0xffff) * sc, m[1] = (float)(v >> 16) * sc;
+            break;
+        }
+        case 3: m[0] = (float)s[idx] * sc, m[1] = (float)s[idx + 1] * sc, m[2] = (float)s[idx + 2] * sc; break;
+        default: {
+            uint2 v = *(const uint2*)(s + idx);
+            m[0] = (float)(v.x & 0xffff) * sc, m[1] = (float)(v.x >> 16) * sc;
+            m[2] = (float)(v.y & 0xffff) * sc, m[3] = (float)(v.y >> 16) * sc;
+        }
+    }
+}
+
+/* GL_LINEAR + CLAMP_TO_EDGE fetch of a 16-bit plane at float texel coordinates u,v (half-texel shift
+ * applied): fp32 weights, v0 + w*(v1-v0), x first then y. */
+DEV f4 sample16_float(const KPlane& p, float u, float v)
+{
+    const float fx = __builtin_floorf(u), fy = __builtin_floorf(v);
+    const float wx = u - fx, wy = v - fy;
+    int         x0 = (int)fx, y0 = (int)fy;
+    const int   x1 = iclamp(x0 + 1, 0, p.w - 1), y1 = iclamp(y0 + 1, 0, p.h - 1);
+    x0             = iclamp(x0, 0, p.w - 1);
+    y0             = iclamp(y0, 0, p.h - 1);
+    float a[4], b[4];
+    load16(p, x0, y0, a);
+    if (wx != 0.0f) {
+        load16(p, x1, y0, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            a[k] = a[k] + wx * (b[k] - a[k]);
+    }
+    if (wy != 0.0f) {
+        float c[4];
+        load16(p, x0, y1, c);
+        if (wx != 0.0f) {
+            load16(p, x1, y1, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                c[k] = c[k] + wx * (b[k] - c[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            a[k] = a[k] + wy * (c[k] - a[k]);
+    }
+    return gl_texel(p.channels, a[0], a[1], a[2], a[3]);
+}
+
+/* texture(sampler, (s,t)) */
+DEV f4 sample_norm(const KPlane& p, float s, float t)
+{
+    if (p.bits == 8) {
+        const int iu = (int)__builtin_rintf(s * p.fw * 256.0f) - 128;
+        const int iv = (int)__builtin_rintf(t * p.fh * 256.0f) - 128;
+        return sample8_fixed(p, iu, iv);
+    }
+    return sample16_float(p, s * p.fw - 0.5f, t * p.fh - 0.5f);
+}
+
+/* KF_UNIT_SCALE: plane 0 maps 1:1 at an integer offset; plane k is w_k/w_0 of it. px,py = plane-0
+ * texel index; rx = w_k/w_0, ry = h_k/h_0 (exact small dyadic ratios for 4:2:x video). */
+DEV f4 sample_unit(const KPlane& p, int px, int py, float rx, float ry)
+{
+    if (p.bits == 8) {
+        const int iu = (int)__builtin_rintf(((float)px + 0.5f) * (rx * 256.0f)) - 128;
+        const int iv = (int)__builtin_rintf(((float)py + 0.5f) * (ry * 256.0f)) - 128;
+        return sample8_fixed(p, iu, iv);
+    }
+    return sample16_float(p, ((float)px + 0.5f) * rx - 0.5f, ((float)py + 0.5f) * ry - 0.5f);
+}
+
+/* ------------------------------------------------------------------ shader.frag restated for gfx950 */
+
+DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+DEV float clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+DEV float fractf(float x) { return x - __builtin_floorf(x); }
+
+/* x / c for a compile-time constant c, correctly rounded in 3 ops instead of the ~10 of a full divide:
+ * q = x*rc, one Newton step on the residual (Markstein). */
+DEV float div_const(float x, float c, float rc)
+{
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, c, x);
+    return __builtin_fmaf(r, rc, q);
+}
+
+/* shader.frag:441-467; internal order x=blue y=green z=red w=alpha */
+DEV f4 ycbcra_to_rgba(float Y, float Cb, float Cr, float A, bool hd)
+{
+    const float yy = 1.164f * (Y * 255.0f - 16.0f);
+    const float cb = Cb * 255.0f - 128.0f, cr = Cr * 255.0f - 128.0f;
+    f4          c;
+    if (hd) {
+        c.z = div_const((yy + 1.793f * cr), 255.0f, 1.0f / 255.0f);
+        c.y = div_const((yy - 0.534f * cr - 0.213f * cb), 255.0f, 1.0f / 255.0f);
+        c.x = div_const((yy + 2.115f * cb), 255.0f, 1.0f / 255.0f);
+    } else {
+        c.z = div_const((yy + 1.596f * cr), 255.0f, 1.0f / 255.0f);
+        c.y = div_const((yy - 0.813f * cr - 0.391f * cb), 255.0f, 1.0f / 255.0f);
+        c.x = div_const((yy + 2.018f * cb), 255.0f, 1.0f / 255.0f);
+    }
+    c.w = A;
+    return c;
+}
+
+/* shader.frag:304-321 */
+DEV f3 rgb2hsv(f3 c)
+{
+    const float st = c.y < c.z ? 0.0f : 1.0f; /* step(c.b, c.g) */
+    const f4    p  = {mixf(c.z, c.y, st), mixf(c.y, c.z, st), mixf(-1.0f, 0.0f, st), mixf(2.0f / 3.0f, -1.0f / 3.0f, st)};
+    const float s2 = c.x < p.x ? 0.0f : 1.0f; /* step(p.x, c.r) */
+    const f4    q  = {mixf(p.x, c.x, s2), p.y, mixf(p.w, p.z, s2), mixf(c.x, p.x, s2)};
+    const float d  = q.x - __builtin_fminf(q.w, q.y);
+    const float e  = 1.0e-10f;
+    return f3{__builtin_fabsf(q.z + (q.w - q.y) / (6.0f * d + e)), d / (q.x + e), q.x};
+}
+DEV f3 hsv2rgb(f3 c)
+{
+    const f3 p = {__builtin_fabsf(fractf(c.x + 1.0f) * 6.0f - 3.0f),
+                  __builtin_fabsf(fractf(c.x + 2.0f / 3.0f) * 6.0f - 3.0f),
+                  __builtin_fabsf(fractf(c.x + 1.0f / 3.0f) * 6.0f - 3.0f)};
+    return f3{c.z * mixf(1.0f, clamp01(p.x - 1.0f), c.y), c.z * mixf(1.0f, clamp01(p.y - 1.0f), c.y),
+              c.z * mixf(1.0f, clamp01(p.z - 1.0f), c.y)};
+}
+
+/* shader.frag:323-383,436-439; colour in internal order */
+__device__ __noinline__ f4 chroma_key(f4 c, const KOp& op)
+{
+    const f3    hsv      = rgb2hsv(f3{c.z, c.y, c.x}); /* c.bgra -> real r,g,b */
+    const float hueDiff  = (0.5f - __builtin_fabsf(__builtin_fabsf(hsv.x - op.ch_target_hue) - 0.5f)) * 2.0f;
+    const float satDiff  = __builtin_fminf(0.0f, op.ch_min_saturation - hsv.y);
+    const float briDiff  = __builtin_fminf(0.0f, op.ch_min_brightness - hsv.z);
+    const float sbScore  = __builtin_fmaxf(briDiff, satDiff);
+    const float hueScore = hueDiff - op.ch_hue_width;
+    const float distance = -hueScore * sbScore;
+    const float dd       = distance * -2.0f + 1.0f;
+    f3          sp       = hsv;
+    float       diff     = hsv.x - op.ch_target_hue;
+    diff                 = diff < -0.5f ? diff + 1.0f : (diff > 0.5f ? diff - 1.0f : diff);
+    const float dist     = __builtin_fabsf(diff) / op.ch_spill;
+    if (dist < 1.0f) {
+        sp.x = diff < 0.0f ? op.ch_target_hue - op.ch_spill : op.ch_target_hue + op.ch_spill;
+        sp.y *= __builtin_fminf(1.0f, dist + op.ch_spill_saturation);
+    }
+    const f3    rgb   = hsv2rgb(sp);
+    const float t     = clamp01((dd - 1.0f) / (op.ch_softness - 1.0f)); /* smoothstep(1, softness, d) */
+    const float alpha = 1.0f - t * t * (3.0f - 2.0f * t);
+    if (op.flags & KF_CHROMA_MASK)
+        return f4{alpha, alpha, alpha, 1.0f};
+    return f4{rgb.z * alpha, rgb.y * alpha, rgb.x * alpha, alpha}; /* back to internal order */
+}
+
+/* shader.frag:76-86 */
+DEV float levels1(float c, const KOp& op)
+{
+    float r = __builtin_fminf(__builtin_fmaxf(c - op.lv_min_input, 0.0f) * op.lv_inv_range, 1.0f);
+    r       = __builtin_amdgcn_exp2f(op.lv_inv_gamma * __builtin_amdgcn_logf(r)); /* pow(r, 1/gamma), r in [0,1] */
+    return mixf(op.lv_min_output, op.lv_max_output, r);
+}
+
+/* shader.frag:48-70 */
+DEV void csb(f4& color, const KOp& op)
+{
+    const bool hd = op.flags & KF_IS_HD;
+    const f3   L  = hd ? f3{0.0722f, 0.7152f, 0.2126f} : f3{0.114f, 0.587f, 0.299f};
+    f3         c  = {color.x, color.y, color.z};
+    if (color.w > 0.0f) {
+        const float ia = 1.0f / color.w;
+        c.x *= ia, c.y *= ia, c.z *= ia;
+    }
+    const f3    b = {c.x * op.brt, c.y * op.brt, c.z * op.brt};
+    const float i = b.x * L.x + b.y * L.y + b.z * L.z;
+    const f3    s = {mixf(i, b.x, op.sat), mixf(i, b.y, op.sat), mixf(i, b.z, op.sat)};
+    color.x       = mixf(0.5f, s.x, op.con) * color.w;
+    color.y       = mixf(0.5f, s.y, op.con) * color.w;
+    color.z       = mixf(0.5f, s.z, op.con) * color.w;
+}
+
+/* shader.frag:114-197 */
+DEV f3 RGBToHSL(f3 color)
+{
+    f3          hsl   = {0.0f, 0.0f, 0.0f};
+    const float fmin  = __builtin_fminf(__builtin_fminf(color.x, color.y), color.z);
+    const float fmax  = __builtin_fmaxf(__builtin_fmaxf(color.x, color.y), color.z);
+    const float delta = fmax - fmin;
+    hsl.z             = (fmax + fmin) / 2.0f;
+    if (delta != 0.0f) {
+        hsl.y              = hsl.z < 0.5f ? delta / (fmax + fmin) : delta / (2.0f - fmax - fmin);
+        const float deltaR = (((fmax - color.x) / 6.0f) + (delta / 2.0f)) / delta;
+        const float deltaG = (((fmax - color.y) / 6.0f) + (delta / 2.0f)) / delta;
+        const float deltaB = (((fmax - color.z) / 6.0f) + (delta / 2.0f)) / delta;
+        if (color.x == fmax)
+            hsl.x = deltaB - deltaG;
+        else if (color.y == fmax)
+            hsl.x = (1.0f / 3.0f) + deltaR - deltaB;
+        else if (color.z == fmax)
+            hsl.x = (2.0f / 3.0f) + deltaG - deltaR;
+        if (hsl.x < 0.0f)
+            hsl.x += 1.0f;
+        else if (hsl.x > 1.0f)
+            hsl.x -= 1.0f;
+    }
+    return hsl;
+}
+DEV float HueToRGB(float f1, float f2, float hue)
+{
+    if (hue < 0.0f)
+        hue += 1.0f;
+    else if (hue > 1.0f)
+        hue -= 1.0f;
+    if ((6.0f * hue) < 1.0f)
+        return f1 + (f2 - f1) * 6.0f * hue;
+    if ((2.0f * hue) < 1.0f)
+        return f2;
+    if ((3.0f * hue) < 2.0f)
+        return f1 + (f2 - f1) * ((2.0f / 3.0f) - hue) * 6.0f;
+    return f1;
+}
+DEV f3 HSLToRGB(f3 hsl)
+{
+    if (hsl.y == 0.0f)
+        return f3{hsl.z, hsl.z, hsl.z};
+    const float f2 = hsl.z < 0.5f ? hsl.z * (1.0f + hsl.y) : (hsl.z + hsl.y) - (hsl.y * hsl.z);
+    const float f1 = 2.0f * hsl.z - f2;
+    return f3{HueToRGB(f1, f2, hsl.x + (1.0f / 3.0f)), HueToRGB(f1, f2, hsl.x), HueToRGB(f1, f2, hsl.x - (1.0f / 3.0f))};
+}
+
+/* shader.frag:208-223 */
+DEV float BlendAddf(float b, float s) { return __builtin_fminf(b + s, 1.0f); }
+DEV float BlendSubstractf(float b, float s) { return __builtin_fmaxf(b + s - 1.0f, 0.0f); }
+DEV float BlendLinearLightf(float b, float s)
+{
+    return s < 0.5f ? BlendSubstractf(b, 2.0f * s) : BlendAddf(b, 2.0f * (s - 0.5f));
+}
+DEV float BlendScreenf(float b, float s) { return 1.0f - ((1.0f - b) * (1.0f - s)); }
+DEV float BlendOverlayf(float b, float s)
+{
+    return b < 0.5f ? (2.0f * b * s) : (1.0f - 2.0f * (1.0f - b) * (1.0f - s));
+}
+DEV float BlendColorDodgef(float b, float s) { return s == 1.0f ? s : __builtin_fminf(b / (1.0f - s), 1.0f); }
+DEV float BlendColorBurnf(float b, float s) { return s == 0.0f ? s : __builtin_fmaxf(1.0f - ((1.0f - b) / s), 0.0f); }
+DEV float BlendVividLightf(float b, float s)
+{
+    return s < 0.5f ? BlendColorBurnf(b, 2.0f * s) : BlendColorDodgef(b, 2.0f * (s - 0.5f));
+}
+DEV float BlendPinLightf(float b, float s)
+{
+    return s < 0.5f ? __builtin_fminf(2.0f * s, b) : __builtin_fmaxf(2.0f * (s - 0.5f), b);
+}
+DEV float BlendHardMixf(float b, float s) { return BlendVividLightf(b, s) < 0.5f ? 0.0f : 1.0f; }
+DEV float BlendReflectf(float b, float s) { return s == 1.0f ? s : __builtin_fminf(b * b / (1.0f - s), 1.0f); }
+
+#define B3(f) f3{f(b.x, s.x), f(b.y, s.y), f(b.z, s.z)}
+#define B3R(f) f3{f(s.x, b.x), f(s.y, b.y), f(s.z, b.z)}
+
+/* shader.frag:387-422 with its aliasing kept: 12 (soft_light) and >= 29 (mix) fall through to normal,
+ * 25 ("contrast") runs BlendHue. b = back, s = fore. The mode is wave-uniform. */
+__device__ __noinline__ f3 get_blend_color(int mode, f3 b, f3 s)
+{
+    switch (mode) {
+        case 1: return f3{__builtin_fmaxf(s.x, b.x), __builtin_fmaxf(s.y, b.y), __builtin_fmaxf(s.z, b.z)};
+        case 2: return f3{__builtin_fminf(s.x, b.x), __builtin_fminf(s.y, b.y), __builtin_fminf(s.z, b.z)};
+        case 3: return f3{b.x * s.x, b.y * s.y, b.z * s.z};
+        case 4: return f3{(b.x + s.x) / 2.0f, (b.y + s.y) / 2.0f, (b.z + s.z) / 2.0f};
+        case 5:
+        case 16: return B3(BlendAddf);
+        case 6:
+        case 17: return B3(BlendSubstractf);
+        case 7: return f3{__builtin_fabsf(b.x - s.x), __builtin_fabsf(b.y - s.y), __builtin_fabsf(b.z - s.z)};
+        case 8:
+            return f3{1.0f - __builtin_fabsf(1.0f - b.x - s.x), 1.0f - __builtin_fabsf(1.0f - b.y - s.y),
+                      1.0f - __builtin_fabsf(1.0f - b.z - s.z)};
+        case 9:
+            return f3{b.x + s.x - 2.0f * b.x * s.x, b.y + s.y - 2.0f * b.y * s.y, b.z + s.z - 2.0f * b.z * s.z};
+        case 10: return B3(BlendScreenf);
+        case 11: return B3(BlendOverlayf);
+        case 13: return B3R(BlendOverlayf);
+        case 14: return B3(BlendColorDodgef);
+        case 15: return B3(BlendColorBurnf);
+        case 18: return B3(BlendLinearLightf);
+        case 19: return B3(BlendVividLightf);
+        case 20: return B3(BlendPinLightf);
+        case 21: return B3(BlendHardMixf);
+        case 22: return B3(BlendReflectf);
+        case 23: return B3R(BlendReflectf);
+        case 24:
+            return f3{__builtin_fminf(b.x, s.x) - __builtin_fmaxf(b.x, s.x) + 1.0f,
+                      __builtin_fminf(b.y, s.y) - __builtin_fmaxf(b.y, s.y) + 1.0f,
+                      __builtin_fminf(b.z, s.z) - __builtin_fmaxf(b.z, s.z) + 1.0f};
+        case 25: {
+            const f3 h = RGBToHSL(b);
+            return HSLToRGB(f3{RGBToHSL(s).x, h.y, h.z});
+        }
+        case 26: {
+            const f3 h = RGBToHSL(b);
+            return HSLToRGB(f3{h.x, RGBToHSL(s).y, h.z});
+        }
+        case 27: {
+            const f3 h = RGBToHSL(s);
+            return HSLToRGB(f3{h.x, h.y, RGBToHSL(b).z});
+        }
+        case 28: {
+            const f3 h = RGBToHSL(b);
+            return HSLToRGB(f3{h.x, h.y, RGBToHSL(s).z});
+        }
+        default: return s;
+    }
+}
+
+/* shader.frag:474-521 from GL texels to the internal (b,g,r,a) vector */
+DEV f4 swizzle_format(int pf, f4 a)
+{
+    switch (pf) {
+        case 0: return f4{a.x, a.x, a.x, 1.0f};
+        case 1: return f4{a.z, a.y, a.x, a.w};
+        case 2: return a;
+        case 3: return f4{a.w, a.x, a.y, a.z};
+        case 4: return f4{a.y, a.z, a.w, a.x};
+        case 7: {
+            const float l = div_const(a.x - 0.065f, 0.859f, 1.0f / 0.859f);
+            return f4{l, l, l, 1.0f};
+        }
+        case 8: return f4{a.z, a.y, a.x, 1.0f};
+        case 9: return f4{a.x, a.y, a.z, 1.0f};
+        default: return f4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+}
+
+/* source colour of a KOP_DRAW_PLANES at normalised (s,t) */
+DEV f4 source_color_norm(const KOp& op, float s, float t)
+{
+    const bool hd = op.flags & KF_IS_HD;
+    switch (op.pixel_format) {
+        case 5:
+            return ycbcra_to_rgba(sample_norm(op.planes[0], s, t).x, sample_norm(op.planes[1], s, t).x,
+                                  sample_norm(op.planes[2], s, t).x, 1.0f, hd);
+        case 6:
+            return ycbcra_to_rgba(sample_norm(op.planes[0], s, t).x, sample_norm(op.planes[1], s, t).x,
+                                  sample_norm(op.planes[2], s, t).x, sample_norm(op.planes[3], s, t).x, hd);
+        case 10: {
+            const float y = sample_norm(op.planes[0], s, t).y;
+            const f4    c = sample_norm(op.planes[1], s, t);
+            return ycbcra_to_rgba(y, c.z, c.x, 1.0f, hd);
+        }
+        default: return swizzle_format(op.pixel_format, sample_norm(op.planes[0], s, t));
+    }
+}
+
+/* same, KF_UNIT_SCALE addressing: (px,py) = plane-0 texel */
+DEV f4 source_color_unit(const KOp& op, int px, int py)
+{
+    const bool   hd = op.flags & KF_IS_HD;
+    const float  w0 = op.planes[0].fw, h0 = op.planes[0].fh;
+#define RX(k) (op.planes[k].fw / w0)
+#define RY(k) (op.planes[k].fh / h0)
+    switch (op.pixel_format) {
+        case 5:
+            return ycbcra_to_rgba(sample_unit(op.planes[0], px, py, 1.0f, 1.0f).x,
+                                  sample_unit(op.planes[1], px, py, RX(1), RY(1)).x,
+                                  sample_unit(op.planes[2], px, py, RX(2), RY(2)).x, 1.0f, hd);
+        case 6:
+            return ycbcra_to_rgba(sample_unit(op.planes[0], px, py, 1.0f, 1.0f).x,
+                                  sample_unit(op.planes[1], px, py, RX(1), RY(1)).x,
+                                  sample_unit(op.planes[2], px, py, RX(2), RY(2)).x,
+                                  sample_unit(op.planes[3], px, py, RX(3), RY(3)).x, hd);
+        case 10: {
+            const float y = sample_unit(op.planes[0], px, py, 1.0f, 1.0f).y;
+            const f4    c = sample_unit(op.planes[1], px, py, RX(1), RY(1));
+            return ycbcra_to_rgba(y, c.z, c.x, 1.0f, hd);
+        }
+        default: return swizzle_format(op.pixel_format, sample_unit(op.planes[0], px, py, 1.0f, 1.0f));
+    }
+#undef RX
+#undef RY
+}
+
+/* shader.frag:523-541 after get_rgba_color: adjustments, keys, opacity, invert, blend; returns the
+ * UNQUANTISED result in internal order. back = current content of the destination surface. */
+DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
+{
+    if (op.flags & KF_CHROMA)
+        color = chroma_key(color, op);
+    if (op.flags & KF_LEVELS) {
+        color.x = levels1(color.x, op);
+        color.y = levels1(color.y, op);
+        color.z = levels1(color.z, op);
+    }
+    if (op.flags & KF_CSB)
+        csb(color, op);
+    if (op.local_key != KS_NONE)
+        color.x *= lkey, color.y *= lkey, color.z *= lkey, color.w *= lkey;
+    if (op.layer_key != KS_NONE)
+        color.x *= ykey, color.y *= ykey, color.z *= ykey, color.w *= ykey;
+    color.x *= op.opacity, color.y *= op.opacity, color.z *= op.opacity, color.w *= op.opacity;
+    if (op.flags & KF_INVERT)
+        color = f4{1.0f - color.x, 1.0f - color.y, 1.0f - color.z, 1.0f - color.w};
+    f4 fore = color;
+    if (op.blend_mode != 0) { /* shader.frag:427-428 */
+        const float ib = 1.0f / (back.w + 0.0000001f), ifo = 1.0f / (fore.w + 0.0000001f);
+        const f3    bc = get_blend_color(op.blend_mode, f3{back.x * ib, back.y * ib, back.z * ib},
+                                      f3{fore.x * ifo, fore.y * ifo, fore.z * ifo});
+        fore.x = bc.x * fore.w, fore.y = bc.y * fore.w, fore.z = bc.z * fore.w;
+    }
+    if (op.flags & KF_ADDITIVE) /* shader.frag:429-433 */
+        return f4{fore.x + back.x, fore.y + back.y, fore.z + back.z, fore.w + back.w};
+    const float ia = 1.0f - fore.w;
+    return f4{fore.x + ia * back.x, fore.y + ia * back.y, fore.z + ia * back.z, fore.w + ia * back.w};
+}
+
+/* ------------------------------------------------------------------ the compositor */
+
+DEV f4 sel4(bool c, f4 a, f4 b) { return f4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
+
+/* General compositor: one output pixel per lane (one wave = 64 consecutive pixels of a row, one
+ * workgroup = 4 rows). FULL = false drops the two extra RGBA surfaces (layer / mix temporaries) from the
+ * register file: the host picks it when the frame has only normal-blend, non-mix layers. Surfaces are
+ * plain scalars selected by value, never arrays, so they stay in VGPRs. */
+template <int BITS, bool FULL>
+__global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
+                                                       int W, int H, int field_mode)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int y    = blockIdx.y * 4 + wave;
+    if (y >= H)
+        return;
+    const int wave_x0 = blockIdx.x * 64;
+    const int wave_x1 = wave_x0 + 64;
+    const int x       = wave_x0 + lane;
+
+    f4    s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    float k0 = 0.0f, k1 = 0.0f;
+
+    const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
+
+    for (int n = 0; n < nops && row_live; ++n) {
+        const KOp& op = ops[n];
+        if (op.kind == KOP_CLEAR) {
+            if (FULL && op.dst == KS_RGBA1) s1 = f4{0, 0, 0, 0};
+            if (FULL && op.dst == KS_RGBA2) s2 = f4{0, 0, 0, 0};
+            if (op.dst == KS_KEY0) k0 = 0.0f;
+            if (op.dst == KS_KEY1) k1 = 0.0f;
+            continue;
+        }
+        /* wave-uniform cull against the op's touched box */
+        if (y < op.y0 || y >= op.y1 || wave_x1 <= op.x0 || wave_x0 >= op.x1)
+            continue;
+        if (x < op.x0 || x >= op.x1)
+            continue;
+
+        f4 color;
+        if (op.kind == KOP_DRAW_SURFACE) {
+            color = FULL ? sel4(op.src_surface == KS_RGBA2, s2, s1) : f4{0, 0, 0, 0};
+        } else if (op.flags & KF_UNIT_SCALE) {
+            color = source_color_unit(op, x + op.unit_dx, y + op.unit_dy);
+        } else {
+            const double dx = (double)x, dy = (double)y;
+            int          t  = 0;
+            if (!(op.flags & KF_RECT)) { /* which triangle covers the pixel centre, if any */
+                bool in = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    in = in && __builtin_fma(op.tri[0].e[k][0], dx, __builtin_fma(op.tri[0].e[k][1], dy, op.tri[0].e[k][2])) >= 0.0;
+                if (!in) {
+                    in = op.ntri > 1;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        in = in && __builtin_fma(op.tri[1].e[k][0], dx, __builtin_fma(op.tri[1].e[k][1], dy, op.tri[1].e[k][2])) >= 0.0;
+                    if (!in)
+                        continue;
+                    t = 1;
+                }
+            }
+            double a[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    a[j][k] = t ? op.tri[1].a[j][k] : op.tri[0].a[j][k];
+            float s  = (float)__builtin_fma(a[0][1], dx, __builtin_fma(a[0][2], dy, a[0][0]));
+            float tt = (float)__builtin_fma(a[1][1], dx, __builtin_fma(a[1][2], dy, a[1][0]));
+            if (op.flags & KF_PROJECTIVE) {
+                const float q = (float)__builtin_fma(a[2][1], dx, __builtin_fma(a[2][2], dy, a[2][0]));
+                s /= q;
+                tt /= q;
+            }
+            color = source_color_norm(op, s, tt);
+        }
+        const float lkey = op.local_key == KS_KEY1 ? k1 : k0;
+        const float ykey = op.layer_key == KS_KEY1 ? k1 : k0;
+        if (op.dst >= KS_KEY0) {
+            /* R8/R16 target (image_mixer.cpp:174-183): background.bgra of a 1-channel texture is
+             * (0,0,r,1); only the red slot of the result is stored. */
+            const bool  one = op.dst == KS_KEY1;
+            const f4    res = shade(op, color, lkey, ykey, f4{0.0f, 0.0f, one ? k1 : k0, 1.0f});
+            const float q   = quantize<BITS>(res.z);
+            k1              = one ? q : k1;
+            k0              = one ? k0 : q;
+        } else {
+            const bool d1 = FULL && op.dst == KS_RGBA1, d2 = FULL && op.dst == KS_RGBA2;
+            f4         back = s0;
+            if (FULL)
+                back = sel4(d1, s1, sel4(d2, s2, s0));
+            f4 res = shade(op, color, lkey, ykey, back);
+            res    = f4{quantize<BITS>(res.x), quantize<BITS>(res.y), quantize<BITS>(res.z), quantize<BITS>(res.w)};
+            if (FULL) {
+                s1 = sel4(d1, res, s1);
+                s2 = sel4(d2, res, s2);
+                s0 = sel4(!d1 && !d2, res, s0);
+            } else {
+                s0 = res;
+            }
+        }
+    }
+
+    /* frame store: memory order B,G,R,A = internal x,y,z,w (texture.cpp:100-105 reads back GL_BGRA) */
+    if (x >= W)
+        return;
+    if (BITS == 8) {
+        ((uint32_t*)out)[(size_t)y * W + x] =
+            to_code<8>(s0.x) | (to_code<8>(s0.y) << 8) | (to_code<8>(s0.z) << 16) | (to_code<8>(s0.w) << 24);
+    } else {
+        ((uint2*)out)[(size_t)y * W + x] = uint2{to_code<16>(s0.x) | (to_code<16>(s0.y) << 16),
+                                                 to_code<16>(s0.z) | (to_code<16>(s0.w) << 16)};
+    }
+}
+
+/* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
+
+extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
+                                             int field_mode, int full, hipStream_t stream)
+{
+    dim3 block(256);
+    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4));
+    if (bits == 8) {
+        if (full)
+            hipLaunchKernelGGL((cghip_composite<8, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+        else
+            hipLaunchKernelGGL((cghip_composite<8, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+    } else {
+        if (full)
+            hipLaunchKernelGGL((cghip_composite<16, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+        else
+            hipLaunchKernelGGL((cghip_composite<16, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,87 @@
+/*
+ * cghip_kops.h -- the per-frame "program" the fused compositor kernel executes.
+ *
+ * The host planner (cghip_plan.cpp) turns each reference draw call (image_kernel::draw,
+ * accelerator/ogl/image/image_kernel.cpp:134-420) into one KOp; the kernel (cghip_kernels.hip) walks the
+ * KOp array once per output pixel and keeps every render surface of the reference renderer
+ * (target / layer / mix / key textures, image_mixer.cpp:95,128,177,187) in registers.
+ * POD only: the array is copied to device memory and read through scalar loads (all fields are
+ * wave-uniform).
+ */
+#ifndef CGHIP_KOPS_H
+#define CGHIP_KOPS_H
+
+#include <stdint.h>
+
+enum KOpKind : int32_t {
+    KOP_CLEAR        = 0, /* surface := 0 (glClearTexImage of a fresh temporary) */
+    KOP_DRAW_PLANES  = 1, /* item draw: sample source planes through the quad */
+    KOP_DRAW_SURFACE = 2  /* full-frame 1:1 draw of a temporary surface (image_mixer.cpp:207-225) */
+};
+
+enum KOpFlags : uint32_t {
+    KF_LEVELS      = 1u << 0,
+    KF_CSB         = 1u << 1,
+    KF_CHROMA      = 1u << 2,
+    KF_CHROMA_MASK = 1u << 3,
+    KF_INVERT      = 1u << 4,
+    KF_IS_HD       = 1u << 5,
+    KF_PROJECTIVE  = 1u << 6, /* texture_q != 1 somewhere: divide s,t by q per pixel */
+    KF_RECT        = 1u << 7, /* axis-aligned quad with one affine map: coverage == bbox, no edge tests */
+    KF_UNIT_SCALE  = 1u << 8, /* KF_RECT and plane 0 maps 1:1 onto output pixels at an integer offset */
+    KF_ADDITIVE    = 1u << 9  /* keyer::additive */
+};
+
+/* register-resident surfaces the kernel has names for */
+enum KSurf : int32_t {
+    KS_NONE = -1,
+    KS_RGBA0 = 0, /* frame target */
+    KS_RGBA1 = 1,
+    KS_RGBA2 = 2,
+    KS_KEY0  = 3, /* 1-channel */
+    KS_KEY1  = 4,
+    KS_COUNT = 5
+};
+
+struct KPlane {
+    const void* ptr;
+    int32_t     w, h;
+    int32_t     channels; /* 1..4 samples per texel */
+    int32_t     bits;     /* 8 or 16 */
+    float       fw, fh;   /* (float)w, (float)h */
+};
+
+/* One triangle of the quad (image_kernel.cpp:383-384) in pixel-index space: pixel (x,y) is covered iff
+ * all three e[k][0]*x + e[k][1]*y + e[k][2] >= 0 (fixed-point edge functions, fill-rule bias folded
+ * into the constant; exact in double). Varyings: v = a[j][0] + a[j][1]*x + a[j][2]*y for
+ * j = s*q, t*q, q. */
+struct KTri {
+    double e[3][3];
+    double a[3][3];
+};
+
+struct KOp {
+    int32_t  kind;
+    uint32_t flags;
+    int32_t  dst;         /* KSurf */
+    int32_t  src_surface; /* KSurf for KOP_DRAW_SURFACE */
+    int32_t  local_key;   /* KSurf or KS_NONE */
+    int32_t  layer_key;
+    int32_t  pixel_format;
+    int32_t  blend_mode;
+    int32_t  nplanes;
+    int32_t  ntri;
+    /* pixels that can be touched: coverage bbox ∩ scissor ∩ frame; [x0,x1) x [y0,y1) */
+    int32_t x0, y0, x1, y1;
+    int32_t unit_dx, unit_dy; /* KF_UNIT_SCALE: source texel = (x + unit_dx, y + unit_dy) */
+    float   opacity;
+    float   lv_min_input, lv_inv_range, lv_inv_gamma, lv_min_output, lv_max_output;
+    float   brt, sat, con;
+    float   ch_target_hue, ch_hue_width, ch_min_saturation, ch_min_brightness, ch_softness, ch_spill,
+        ch_spill_saturation;
+    float   pad_[3];
+    KPlane  planes[4];
+    KTri    tri[2];
+};
+
+#endif

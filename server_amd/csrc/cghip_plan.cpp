@@ -1,0 +1,472 @@
+/*
+ * cghip_plan.cpp -- host planner: reference draw calls -> KOp program for the fused kernel.
+ *
+ * Restates, for the HIP path, the host part of image_kernel::draw
+ * (accelerator/ogl/image/image_kernel.cpp:134-375: early-outs, crop / perspective / rotate / translate of
+ * the quad, off-screen cull, uniforms, scissor, projective q) and the fixed-function stage that follows it
+ * on a GL device (viewport transform, 24.8 sub-pixel snapping, two triangles (0,1,2),(0,2,3) with the
+ * top-left fill rule, per-triangle affine varyings). Also maps the renderer's temporaries
+ * (image_mixer.cpp:128,177,187) onto the kernel's register surfaces by liveness.
+ * Pure host code: no HIP calls, unit-testable without a GPU.
+ */
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "cghip_internal.h"
+
+namespace cghip {
+
+namespace {
+
+struct vtx {
+    double vx, vy, s, t, r, q;
+};
+
+bool coords_equal(const cghip_coord* a, const double ref[4][4])
+{ /* frame_geometry::coord::operator== over a quad (geometry.cpp:35-39) */
+    for (int i = 0; i < 4; ++i)
+        if (!(a[i].vertex_x == ref[i][0] && a[i].vertex_y == ref[i][1] && a[i].texture_x == ref[i][2] &&
+              a[i].texture_y == ref[i][3] && a[i].texture_r == 0.0 && a[i].texture_q == 1.0))
+            return false;
+    return true;
+}
+
+const double kDefault[4][4]      = {{0, 0, 0, 0}, {1, 0, 1, 0}, {1, 1, 1, 1}, {0, 1, 0, 1}}; /* geometry.cpp:64-76 */
+const double kDefaultVflip[4][4] = {{0, 0, 0, 1}, {1, 0, 1, 1}, {1, 1, 1, 0}, {0, 1, 0, 0}}; /* geometry.cpp:77-89 */
+
+bool line_intersection(double p0x, double p0y, double p1x, double p1y, double p2x, double p2y, double p3x,
+                       double p3y, double& rx, double& ry)
+{ /* image_kernel.cpp:46-74 */
+    const double s1x = p1x - p0x, s1y = p1y - p0y, s2x = p3x - p2x, s2y = p3y - p2y;
+    const double den = -s2x * s1y + s1x * s2y;
+    const double s   = (-s1y * (p0x - p2x) + s1x * (p0y - p2y)) / den;
+    const double t   = (s2x * (p0y - p2y) - s2y * (p0x - p2x)) / den;
+    if (s >= 0 && s <= 1 && t >= 0 && t <= 1) {
+        rx = p0x + t * s1x;
+        ry = p0y + t * s1y;
+        return true;
+    }
+    return false;
+}
+
+double hyp(double x1, double y1, double x2, double y2) { return std::sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
+
+/* Quad after image_kernel::draw's vertex math; false = the reference returns before drawing. */
+bool transform_quad(const cghip_draw& d, vtx out[4])
+{
+    const cghip_transform& t = d.transform;
+    for (int i = 0; i < 4; ++i)
+        out[i] = vtx{d.coords[i].vertex_x,  d.coords[i].vertex_y,  d.coords[i].texture_x,
+                     d.coords[i].texture_y, d.coords[i].texture_r, d.coords[i].texture_q};
+    const bool is_default = coords_equal(d.coords, kDefault) || coords_equal(d.coords, kDefaultVflip); /* :158-159 */
+
+    const double pers[4][2] = {{t.pers_ul[0], t.pers_ul[1]},
+                               {t.pers_ur[0] - 1.0, t.pers_ur[1]},
+                               {t.pers_lr[0] - 1.0, t.pers_lr[1] - 1.0},
+                               {t.pers_ll[0], t.pers_ll[1] - 1.0}}; /* :164-169 */
+    const double aspect = d.aspect_ratio, ca = std::cos(t.angle), sa = std::sin(t.angle);
+    for (int i = 0; i < 4; ++i) {
+        vtx& c = out[i];
+        if (is_default) {
+            c.vx = std::min(std::max(c.vx, t.crop_ul[0]), t.crop_lr[0]); /* do_crop :171-185 */
+            c.vy = std::min(std::max(c.vy, t.crop_ul[1]), t.crop_lr[1]);
+            c.s  = std::min(std::max(c.s, t.crop_ul[0]), t.crop_lr[0]);
+            c.t  = std::min(std::max(c.t, t.crop_ul[1]), t.crop_lr[1]);
+            c.vx += pers[i][0]; /* do_perspective :186-194 */
+            c.vy += pers[i][1];
+        }
+        const double ox = (c.vx - t.anchor[0]) * t.fill_scale[0]; /* rotate :195-201 */
+        const double oy = (c.vy - t.anchor[1]) * t.fill_scale[1] / aspect;
+        c.vx            = ox * ca - oy * sa;
+        c.vy            = (ox * sa + oy * ca) * aspect;
+        c.vx += t.fill_translation[0]; /* move :202-205 */
+        c.vy += t.fill_translation[1];
+    }
+    bool l = true, r = true, a = true, b = true; /* is_outside_screen :97-107 */
+    for (int i = 0; i < 4; ++i) {
+        l = l && out[i].vx < 0.0;
+        r = r && out[i].vx > 1.0;
+        a = a && out[i].vy < 0.0;
+        b = b && out[i].vy > 1.0;
+    }
+    if (l || r || a || b)
+        return false;
+
+    /* projective q :335-375 */
+    const double *cu = t.crop_ul, *cl = t.crop_lr;
+    double        ix, iy;
+    if (line_intersection(pers[0][0] + cu[0], pers[0][1] + cu[1], pers[2][0] + cl[0], pers[2][1] + cl[1],
+                          pers[1][0] + cl[0], pers[1][1] + cu[1], pers[3][0] + cu[0], pers[3][1] + cl[1], ix, iy) &&
+        is_default) {
+        const double d0   = hyp(pers[3][0] + cu[0], pers[3][1] + cl[1], ix, iy);
+        const double d1   = hyp(pers[2][0] + cl[0], pers[2][1] + cl[1], ix, iy);
+        const double d2   = hyp(pers[1][0] + cl[0], pers[1][1] + cu[1], ix, iy);
+        const double d3   = hyp(pers[0][0] + cu[0], pers[0][1] + cu[1], ix, iy);
+        const double q[4] = {(d3 + d1) / d1, (d2 + d0) / d0, (d1 + d3) / d3, (d0 + d2) / d2};
+        for (int i = 0; i < 4; ++i) {
+            out[i].q = q[i];
+            out[i].s *= q[i];
+            out[i].t *= q[i];
+        }
+    }
+    return true;
+}
+
+struct raster_tri {
+    int64_t X[3], Y[3];
+    double  fx[3], fy[3], attr[3][3];
+    bool    valid;
+};
+
+/* vertex stage (shader.vert:8-16) + viewport + snapping for one triangle */
+raster_tri setup_tri(const vtx q[4], const int idx[3], int W, int H)
+{
+    raster_tri tr{};
+    for (int i = 0; i < 3; ++i) {
+        const vtx&  v  = q[idx[i]];
+        const float px = (float)v.vx, py = (float)v.vy; /* GL_DOUBLE attribs narrowed to float */
+        const float nx = px * 2.0f - 1.0f, ny = py * 2.0f - 1.0f;
+        const float wx = nx * ((float)W * 0.5f) + ((float)W * 0.5f);
+        const float wy = ny * ((float)H * 0.5f) + ((float)H * 0.5f);
+        tr.fx[i]       = (double)wx - 0.5; /* pixel-centre space */
+        tr.fy[i]       = (double)wy - 0.5;
+        tr.X[i]        = (int64_t)std::llrint(tr.fx[i] * 256.0);
+        tr.Y[i]        = (int64_t)std::llrint(tr.fy[i] * 256.0);
+        tr.attr[i][0]  = (double)(float)v.s;
+        tr.attr[i][1]  = (double)(float)v.t;
+        tr.attr[i][2]  = (double)(float)v.q;
+    }
+    const int64_t area = (tr.X[1] - tr.X[0]) * (tr.Y[2] - tr.Y[0]) - (tr.Y[1] - tr.Y[0]) * (tr.X[2] - tr.X[0]);
+    tr.valid           = area != 0;
+    if (area < 0) { /* no face culling in the reference: orient clockwise-on-screen */
+        std::swap(tr.X[1], tr.X[2]);
+        std::swap(tr.Y[1], tr.Y[2]);
+        std::swap(tr.fx[1], tr.fx[2]);
+        std::swap(tr.fy[1], tr.fy[2]);
+        for (int k = 0; k < 3; ++k)
+            std::swap(tr.attr[1][k], tr.attr[2][k]);
+    }
+    return tr;
+}
+
+void emit_tri(const raster_tri& tr, KTri& k)
+{
+    for (int e = 0; e < 3; ++e) {
+        const int     a = e, b = (e + 1) % 3;
+        const int64_t dx = tr.X[b] - tr.X[a], dy = tr.Y[b] - tr.Y[a];
+        /* E(px,py) = dx*(py-ay) - dy*(px-ax) with px = 256x, py = 256y; top-left: ties belong to edges that
+           run upwards (left) or left-to-right horizontally (top) */
+        const bool    top_left = (dy < 0) || (dy == 0 && dx > 0);
+        const int64_t c        = -dx * tr.Y[a] + dy * tr.X[a] + (top_left ? 0 : -1);
+        k.e[e][0]              = (double)(-dy * 256);
+        k.e[e][1]              = (double)(dx * 256);
+        k.e[e][2]              = (double)c;
+    }
+    /* varyings: plane through the three vertices, in pixel-index space */
+    const double x0 = tr.fx[0], y0 = tr.fy[0];
+    const double ax = tr.fx[1] - x0, ay = tr.fy[1] - y0, bx = tr.fx[2] - x0, by = tr.fy[2] - y0;
+    const double det = ax * by - ay * bx;
+    const double inv = det != 0.0 ? 1.0 / det : 0.0;
+    for (int j = 0; j < 3; ++j) {
+        const double d1 = tr.attr[1][j] - tr.attr[0][j], d2 = tr.attr[2][j] - tr.attr[0][j];
+        const double gx = (d1 * by - d2 * ay) * inv;
+        const double gy = (d2 * ax - d1 * bx) * inv;
+        k.a[j][1]       = gx;
+        k.a[j][2]       = gy;
+        k.a[j][0]       = tr.attr[0][j] - gx * x0 - gy * y0;
+    }
+}
+
+int ceil_div256(int64_t v) { return (int)((v >= 0) ? (v + 255) / 256 : -((-v) / 256)); }
+int floor_div256(int64_t v) { return (int)((v >= 0) ? v / 256 : -((-v + 255) / 256)); }
+
+} // namespace
+
+/* One reference draw -> one KOp. Returns 1 emitted, 0 skipped (reference early-out), <0 error. */
+static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
+{
+    const double epsilon = 0.001; /* image_kernel.cpp:136 */
+    const bool   from_surface = d.source_surface >= 0;
+    if ((!from_surface && d.nplanes == 0) || d.target < 0) /* :140-142 */
+        return 0;
+    if (d.transform.opacity < epsilon) /* :144-146 */
+        return 0;
+    if (d.ncoords == 0) /* :150-152 */
+        return 0;
+    if (d.ncoords != 4)
+        return fail(CGHIP_ERR_INVALID, "a quad needs exactly 4 coordinates (geometry.cpp:46-47)");
+    vtx q[4];
+    if (!transform_quad(d, q)) /* :220 */
+        return 0;
+    if (!d.geometry_is_quad) /* :378,413 */
+        return 0;
+
+    const cghip_transform& t = d.transform;
+    const int              W = fmt.width, H = fmt.height;
+    std::memset(&op, 0, sizeof op);
+    op.kind         = from_surface ? KOP_DRAW_SURFACE : KOP_DRAW_PLANES;
+    op.pixel_format = from_surface ? (int)CGHIP_PF_BGRA : d.pixel_format;
+    op.nplanes      = from_surface ? 0 : d.nplanes;
+    op.blend_mode   = t.is_key ? CGHIP_BLEND_NORMAL : d.blend_mode; /* :270-272 */
+    if (op.blend_mode == 12 || op.blend_mode >= 29 || op.blend_mode < 0)
+        op.blend_mode = 0; /* shader.frag:403,421: soft_light and mix execute BlendNormal */
+    op.opacity = (float)(t.is_key ? 1.0 : t.opacity); /* :252 */
+    if (d.keyer == CGHIP_KEYER_ADDITIVE)
+        op.flags |= KF_ADDITIVE;
+    if (t.invert)
+        op.flags |= KF_INVERT;
+    if (t.chroma_enable) { /* :254-266 */
+        op.flags |= KF_CHROMA | (t.chroma_show_mask ? KF_CHROMA_MASK : 0u);
+        op.ch_target_hue       = (float)(t.chroma_target_hue / 360.0);
+        op.ch_hue_width        = (float)t.chroma_hue_width;
+        op.ch_min_saturation   = (float)t.chroma_min_saturation;
+        op.ch_min_brightness   = (float)t.chroma_min_brightness;
+        op.ch_softness         = (float)(1.0 + t.chroma_softness);
+        op.ch_spill            = (float)(t.chroma_spill_suppress / 360.0);
+        op.ch_spill_saturation = (float)t.chroma_spill_suppress_saturation;
+    }
+    if (t.levels_min_input > epsilon || t.levels_max_input < 1.0 - epsilon || t.levels_min_output > epsilon ||
+        t.levels_max_output < 1.0 - epsilon || std::fabs(t.levels_gamma - 1.0) > epsilon) { /* :282-293 */
+        op.flags |= KF_LEVELS;
+        op.lv_min_input  = (float)t.levels_min_input;
+        op.lv_inv_range  = 1.0f / ((float)t.levels_max_input - (float)t.levels_min_input);
+        op.lv_inv_gamma  = 1.0f / (float)t.levels_gamma;
+        op.lv_min_output = (float)t.levels_min_output;
+        op.lv_max_output = (float)t.levels_max_output;
+    }
+    if (std::fabs(t.brightness - 1.0) > epsilon || std::fabs(t.saturation - 1.0) > epsilon ||
+        std::fabs(t.contrast - 1.0) > epsilon) { /* :295-305 */
+        op.flags |= KF_CSB;
+        op.brt = (float)t.brightness;
+        op.sat = (float)t.saturation;
+        op.con = (float)t.contrast;
+    }
+    if (!from_surface) {
+        for (int n = 0; n < d.nplanes; ++n) {
+            const cghip_plane* p = d.planes[n];
+            if (!p)
+                return fail(CGHIP_ERR_INVALID, "draw references a null plane");
+            op.planes[n] = KPlane{p->dptr, p->width, p->height, p->channels, p->bits, (float)p->width, (float)p->height};
+        }
+        if (d.planes[0]->height > 700) /* :248 */
+            op.flags |= KF_IS_HD;
+    } else if (H > 700) {
+        op.flags |= KF_IS_HD; /* the temporary is frame-sized; unused by the bgra path anyway */
+    }
+
+    /* scissor :312-329 (window origin = memory row 0: FBO textures are not flipped) */
+    int sx0 = 0, sy0 = 0, sx1 = W, sy1 = H;
+    if (t.clip_translation[0] > DBL_EPSILON || t.clip_translation[1] > DBL_EPSILON ||
+        t.clip_scale[0] < 1.0 - DBL_EPSILON || t.clip_scale[1] < 1.0 - DBL_EPSILON) {
+        const int x = (int)(t.clip_translation[0] * (double)W), y = (int)(t.clip_translation[1] * (double)H);
+        const int w = std::max(0, (int)(t.clip_scale[0] * (double)W)), h = std::max(0, (int)(t.clip_scale[1] * (double)H));
+        sx0 = std::max(sx0, x), sy0 = std::max(sy0, y);
+        sx1 = std::min(sx1, x + w), sy1 = std::min(sy1, y + h);
+    }
+
+    /* rasteriser setup */
+    static const int idx[2][3] = {{0, 1, 2}, {0, 2, 3}}; /* :383-384 */
+    raster_tri       tr[2]     = {setup_tri(q, idx[0], W, H), setup_tri(q, idx[1], W, H)};
+    int64_t          xmin = INT64_MAX, xmax = INT64_MIN, ymin = INT64_MAX, ymax = INT64_MIN;
+    op.ntri = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!tr[k].valid)
+            continue;
+        for (int i = 0; i < 3; ++i) {
+            if (std::llabs(tr[k].X[i]) > (1ll << 24) || std::llabs(tr[k].Y[i]) > (1ll << 24))
+                return fail(CGHIP_ERR_UNSUPPORTED, "quad vertex further than 65536 px from the frame origin");
+            xmin = std::min(xmin, tr[k].X[i]), xmax = std::max(xmax, tr[k].X[i]);
+            ymin = std::min(ymin, tr[k].Y[i]), ymax = std::max(ymax, tr[k].Y[i]);
+        }
+        emit_tri(tr[k], op.tri[op.ntri++]);
+    }
+    if (op.ntri == 0)
+        return 0; /* zero-area quad: nothing rasterises */
+    if (op.ntri == 1)
+        op.tri[1] = op.tri[0];
+
+    /* axis-aligned parallelogram with a single affine map: coverage is exactly a pixel rectangle */
+    bool rect = tr[0].valid && tr[1].valid;
+    if (rect) {
+        const float vx[4] = {(float)q[0].vx, (float)q[1].vx, (float)q[2].vx, (float)q[3].vx};
+        const float vy[4] = {(float)q[0].vy, (float)q[1].vy, (float)q[2].vy, (float)q[3].vy};
+        const bool  a1 = vy[0] == vy[1] && vx[1] == vx[2] && vy[2] == vy[3] && vx[3] == vx[0];
+        const bool  a2 = vx[0] == vx[1] && vy[1] == vy[2] && vx[2] == vx[3] && vy[3] == vy[0];
+        rect           = a1 || a2;
+        const double as[4][3] = {{(double)(float)q[0].s, (double)(float)q[0].t, (double)(float)q[0].q},
+                                 {(double)(float)q[1].s, (double)(float)q[1].t, (double)(float)q[1].q},
+                                 {(double)(float)q[2].s, (double)(float)q[2].t, (double)(float)q[2].q},
+                                 {(double)(float)q[3].s, (double)(float)q[3].t, (double)(float)q[3].q}};
+        for (int j = 0; j < 3 && rect; ++j)
+            rect = std::fabs((as[0][j] + as[2][j]) - (as[1][j] + as[3][j])) < 1e-12;
+    }
+    bool projective = false;
+    for (int i = 0; i < 4; ++i)
+        projective = projective || (float)q[i].q != 1.0f;
+    if (projective)
+        op.flags |= KF_PROJECTIVE;
+
+    int bx0, by0, bx1, by1;
+    if (rect) {
+        op.flags |= KF_RECT;
+        bx0 = ceil_div256(xmin), bx1 = ceil_div256(xmax); /* left/top inclusive, right/bottom exclusive */
+        by0 = ceil_div256(ymin), by1 = ceil_div256(ymax);
+    } else {
+        bx0 = floor_div256(xmin), bx1 = ceil_div256(xmax) + 1;
+        by0 = floor_div256(ymin), by1 = ceil_div256(ymax) + 1;
+    }
+    op.x0 = std::max(bx0, sx0), op.x1 = std::min(bx1, sx1);
+    op.y0 = std::max(by0, sy0), op.y1 = std::min(by1, sy1);
+    if (op.x0 >= op.x1 || op.y0 >= op.y1)
+        return 0; /* fully clipped: the GL draw touches no pixel */
+
+    /* 1:1 mapping at an integer offset (full-screen video layers, crops, clips) */
+    if (rect && !projective && !from_surface) {
+        const KTri&  m  = op.tri[0];
+        const double w0 = (double)op.planes[0].w, h0 = (double)op.planes[0].h;
+        auto u = [&](double x, double y) { return (m.a[0][0] + m.a[0][1] * x + m.a[0][2] * y) * w0 - 0.5; };
+        auto v = [&](double x, double y) { return (m.a[1][0] + m.a[1][1] * x + m.a[1][2] * y) * h0 - 0.5; };
+        const double xa = op.x0, xb = op.x1 - 1, ya = op.y0, yb = op.y1 - 1;
+        const double du = u(xa, ya) - xa, dv = v(xa, ya) - ya;
+        const double tol = 1e-3;
+        const bool   ok  = std::fabs(du - std::round(du)) < tol && std::fabs(dv - std::round(dv)) < tol &&
+                        std::fabs((u(xb, yb) - xb) - du) < tol && std::fabs((v(xb, yb) - yb) - dv) < tol &&
+                        std::fabs((u(xb, ya) - xb) - du) < tol && std::fabs((v(xa, yb) - yb) - dv) < tol &&
+                        std::fabs((u(xa, yb) - xa) - du) < tol && std::fabs((v(xb, ya) - ya) - dv) < tol;
+        if (ok) {
+            op.flags |= KF_UNIT_SCALE;
+            op.unit_dx = (int)std::llround(du);
+            op.unit_dy = (int)std::llround(dv);
+        }
+    }
+    return 1;
+}
+
+int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces, const cghip_draw* draws,
+               int ndraws, frame_plan* out)
+{
+    out->ops.clear();
+    out->planes.clear();
+    out->full = false;
+    if (!fmt || fmt->width <= 0 || fmt->height <= 0 || (fmt->bits != 8 && fmt->bits != 16))
+        return fail(CGHIP_ERR_INVALID, "bad cghip_format");
+    if (nsurfaces < 1 || nsurfaces > CGHIP_MAX_SURFACES || !surfaces || surfaces[0].channels != 4)
+        return fail(CGHIP_ERR_INVALID, "surface 0 must be the 4-channel frame target");
+    if (ndraws > 0 && !draws)
+        return fail(CGHIP_ERR_INVALID, "null draw list");
+
+    /* pass 1: resolve every draw */
+    std::vector<KOp> resolved((size_t)ndraws);
+    std::vector<int> emitted((size_t)ndraws, 0);
+    auto             slot_ok = [&](int s, bool allow_none) { return (allow_none && s < 0) || (s >= 0 && s < nsurfaces); };
+    for (int i = 0; i < ndraws; ++i) {
+        const cghip_draw& d = draws[i];
+        if (!slot_ok(d.target, false) || !slot_ok(d.local_key, true) || !slot_ok(d.layer_key, true) ||
+            !slot_ok(d.source_surface, true))
+            return fail(CGHIP_ERR_INVALID, "draw references a surface slot out of range");
+        if ((d.local_key >= 0 && surfaces[d.local_key].channels != 1) ||
+            (d.layer_key >= 0 && surfaces[d.layer_key].channels != 1) ||
+            (d.source_surface >= 0 && surfaces[d.source_surface].channels != 4))
+            return fail(CGHIP_ERR_INVALID, "key surfaces have 1 channel, source surfaces 4");
+        if (d.source_surface < 0 && (d.nplanes < 0 || d.nplanes > 4))
+            return fail(CGHIP_ERR_INVALID, "nplanes out of range");
+        const int rc = resolve_draw(*fmt, d, resolved[(size_t)i]);
+        if (rc < 0)
+            return rc;
+        emitted[(size_t)i] = rc;
+    }
+
+    /* pass 2: last use of every surface slot among emitted draws */
+    std::vector<int> last_use((size_t)nsurfaces, -1);
+    for (int i = 0; i < ndraws; ++i) {
+        if (!emitted[(size_t)i])
+            continue;
+        const cghip_draw& d = draws[i];
+        for (int s : {d.target, d.local_key, d.layer_key, d.source_surface})
+            if (s >= 0)
+                last_use[(size_t)s] = i;
+    }
+
+    /* pass 3: bind slots to register surfaces, emitting a CLEAR at first touch (fresh textures are cleared,
+       device.cpp:207-209) */
+    std::vector<int> reg((size_t)nsurfaces, KS_NONE);
+    int              owner[KS_COUNT];
+    for (int& o : owner)
+        o = -1;
+    reg[0]          = KS_RGBA0;
+    owner[KS_RGBA0] = 0;
+    auto bind = [&](int slot, int at) -> int {
+        if (slot < 0)
+            return KS_NONE;
+        if (reg[(size_t)slot] != KS_NONE)
+            return reg[(size_t)slot];
+        const int lo = surfaces[slot].channels == 4 ? KS_RGBA1 : KS_KEY0;
+        const int hi = surfaces[slot].channels == 4 ? KS_RGBA2 : KS_KEY1;
+        for (int r = lo; r <= hi; ++r) {
+            if (owner[r] >= 0 && last_use[(size_t)owner[r]] < at) { /* previous tenant is dead */
+                reg[(size_t)owner[r]] = KS_NONE;
+                owner[r]              = -1;
+            }
+            if (owner[r] < 0) {
+                owner[r]          = slot;
+                reg[(size_t)slot] = r;
+                KOp c;
+                std::memset(&c, 0, sizeof c);
+                c.kind = KOP_CLEAR;
+                c.dst  = r;
+                out->ops.push_back(c);
+                if (r == KS_RGBA1 || r == KS_RGBA2)
+                    out->full = true;
+                return r;
+            }
+        }
+        return -100;
+    };
+    for (int i = 0; i < ndraws; ++i) {
+        if (!emitted[(size_t)i])
+            continue;
+        const cghip_draw& d  = draws[i];
+        KOp&              op = resolved[(size_t)i];
+        /* inputs first: a key consumed by this draw must not lose its register to this draw's target */
+        op.src_surface = bind(d.source_surface, i);
+        op.local_key   = bind(d.local_key, i);
+        op.layer_key   = bind(d.layer_key, i);
+        op.dst         = bind(d.target, i);
+        if (op.src_surface == -100 || op.local_key == -100 || op.layer_key == -100 || op.dst == -100)
+            return fail(CGHIP_ERR_UNSUPPORTED,
+                        "frame needs more than 2 live RGBA temporaries or 2 live key textures at once");
+        if (surfaces[d.target].channels == 1 && d.source_surface >= 0)
+            return fail(CGHIP_ERR_INVALID, "surface-to-key draws do not exist in the reference renderer");
+        out->ops.push_back(op);
+        if (d.source_surface < 0)
+            for (int n = 0; n < d.nplanes; ++n)
+                out->planes.push_back(const_cast<cghip_plane*>(d.planes[n]));
+    }
+    return CGHIP_OK;
+}
+
+} // namespace cghip
+
+/* Introspection for host-logic tests (no GPU needed): plans a frame and copies out the KOps. */
+extern "C" int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces,
+                                const cghip_draw* draws, int ndraws, void* kops_out, int capacity, int* nops,
+                                int* full)
+{
+    cghip::frame_plan plan;
+    const int         rc = cghip::plan_frame(fmt, surfaces, nsurfaces, draws, ndraws, &plan);
+    if (rc != CGHIP_OK)
+        return rc;
+    if (nops)
+        *nops = (int)plan.ops.size();
+    if (full)
+        *full = plan.full ? 1 : 0;
+    if (kops_out) {
+        const int n = std::min(capacity, (int)plan.ops.size());
+        std::memcpy(kops_out, plan.ops.data(), (size_t)n * sizeof(KOp));
+    }
+    return CGHIP_OK;
+}
+
+extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }

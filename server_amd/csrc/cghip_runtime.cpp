@@ -1,0 +1,535 @@
+/*
+ * cghip_runtime.cpp -- device, pools, planes, mixers and tickets behind the C ABI (include/cghip.h).
+ *
+ * HIP counterpart of accelerator/ogl/util/device.cpp: where the reference funnels every channel through
+ * ONE GL context on ONE thread (device.cpp:82-142) and polls a fence every 2 ms for readback
+ * (:264-302), this runtime gives each device an upload stream shared by producer threads, each mixer
+ * (= channel) its own compute/readback stream, and completes frames with hipEvents. Pools are keyed by
+ * byte size like the reference's (device.cpp:194-233) and grow instead of blocking.
+ */
+#include <cstdio>
+#include <cstring>
+
+#include "cghip_internal.h"
+
+namespace cghip {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+int  fail(int status, const std::string& msg)
+{
+    g_err = msg;
+    return status;
+}
+int fail_hip(hipError_t e, const char* what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return CGHIP_ERR_HIP;
+}
+
+static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+} // namespace cghip
+
+using namespace cghip;
+
+/* ------------------------------------------------------------------ pools */
+
+int cghip_device::dev_alloc(size_t bytes, void** out)
+{
+    bytes = round_up(bytes ? bytes : 1, 256);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto                        it = device_pool.free_.find(bytes);
+        if (it != device_pool.free_.end()) {
+            *out = it->second;
+            device_pool.free_.erase(it);
+            device_pool.bytes_free -= bytes;
+            return CGHIP_OK;
+        }
+    }
+    CGHIP_TRY_HIP(hipSetDevice(gpu));
+    CGHIP_TRY_HIP(hipMalloc(out, bytes));
+    std::lock_guard<std::mutex> g(mu);
+    device_pool.bytes_total += bytes;
+    device_pool.count_total++;
+    return CGHIP_OK;
+}
+void cghip_device::dev_free(void* p, size_t bytes)
+{
+    if (!p)
+        return;
+    bytes = round_up(bytes ? bytes : 1, 256);
+    std::lock_guard<std::mutex> g(mu);
+    device_pool.free_.emplace(bytes, p);
+    device_pool.bytes_free += bytes;
+}
+int cghip_device::pinned_alloc(size_t bytes, void** out)
+{
+    bytes = round_up(bytes ? bytes : 1, 4096);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto                        it = pinned_pool.free_.find(bytes);
+        if (it != pinned_pool.free_.end()) {
+            *out = it->second;
+            pinned_pool.free_.erase(it);
+            pinned_pool.bytes_free -= bytes;
+            return CGHIP_OK;
+        }
+    }
+    CGHIP_TRY_HIP(hipSetDevice(gpu));
+    CGHIP_TRY_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    std::lock_guard<std::mutex> g(mu);
+    pinned_pool.bytes_total += bytes;
+    pinned_pool.count_total++;
+    return CGHIP_OK;
+}
+void cghip_device::pinned_free(void* p, size_t bytes)
+{
+    if (!p)
+        return;
+    bytes = round_up(bytes ? bytes : 1, 4096);
+    std::lock_guard<std::mutex> g(mu);
+    pinned_pool.free_.emplace(bytes, p);
+    pinned_pool.bytes_free += bytes;
+}
+
+/* ------------------------------------------------------------------ C ABI */
+
+extern "C" {
+
+const char* cghip_last_error(void) { return g_err.c_str(); }
+int         cghip_abi_version(void) { return CGHIP_ABI_VERSION; }
+
+int cghip_device_count(int* count)
+{
+    if (!count)
+        return fail(CGHIP_ERR_INVALID, "count is null");
+    int        n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        (void)hipGetLastError();
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return CGHIP_OK;
+}
+
+int cghip_device_create(int gpu_index, cghip_device** out)
+{
+    if (!out)
+        return fail(CGHIP_ERR_INVALID, "out is null");
+    *out  = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return fail(CGHIP_ERR_NO_DEVICE, "no HIP device visible (the GL reference throws not_supported here)");
+    }
+    if (gpu_index < 0 || gpu_index >= n)
+        return fail(CGHIP_ERR_INVALID, "gpu_index out of range");
+    CGHIP_TRY_HIP(hipSetDevice(gpu_index));
+    hipDeviceProp_t prop;
+    CGHIP_TRY_HIP(hipGetDeviceProperties(&prop, gpu_index));
+    cghip_device* d = new cghip_device();
+    d->gpu          = gpu_index;
+    d->name         = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    hipError_t e    = hipStreamCreateWithFlags(&d->upload_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete d;
+        return fail_hip(e, "hipStreamCreateWithFlags");
+    }
+    *out = d;
+    return CGHIP_OK;
+}
+
+int cghip_device_gc(cghip_device* dev)
+{ /* device::gc (device.cpp:418-436): drop everything the pools hold */
+    if (!dev)
+        return fail(CGHIP_ERR_INVALID, "dev is null");
+    std::multimap<size_t, void*> d, p;
+    {
+        std::lock_guard<std::mutex> g(dev->mu);
+        d.swap(dev->device_pool.free_);
+        p.swap(dev->pinned_pool.free_);
+        dev->device_pool.bytes_total -= dev->device_pool.bytes_free;
+        dev->pinned_pool.bytes_total -= dev->pinned_pool.bytes_free;
+        dev->device_pool.count_total -= d.size();
+        dev->pinned_pool.count_total -= p.size();
+        dev->device_pool.bytes_free = dev->pinned_pool.bytes_free = 0;
+    }
+    CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
+    CGHIP_TRY_HIP(hipDeviceSynchronize());
+    for (auto& kv : d)
+        (void)hipFree(kv.second);
+    for (auto& kv : p)
+        (void)hipHostFree(kv.second);
+    return CGHIP_OK;
+}
+
+int cghip_device_destroy(cghip_device* dev)
+{
+    if (!dev)
+        return CGHIP_OK;
+    int rc = cghip_device_gc(dev);
+    if (dev->upload_stream)
+        (void)hipStreamDestroy(dev->upload_stream);
+    delete dev;
+    return rc;
+}
+
+int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
+{ /* device::info (device.cpp:335-416) as JSON instead of a wptree */
+    if (!dev || !json || capacity == 0)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(dev->gpu);
+    (void)hipMemGetInfo(&free_b, &total_b);
+    std::lock_guard<std::mutex> g(dev->mu);
+    int n = snprintf(json, capacity,
+                     "{\"gpu\":%d,\"name\":\"%s\",\"hbm_total_bytes\":%zu,\"hbm_free_bytes\":%zu,"
+                     "\"device_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
+                     "\"pinned_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
+                     "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld}",
+                     dev->gpu, dev->name.c_str(), total_b, free_b, dev->device_pool.count_total,
+                     dev->device_pool.bytes_total, dev->device_pool.bytes_free, dev->pinned_pool.count_total,
+                     dev->pinned_pool.bytes_total, dev->pinned_pool.bytes_free, (long long)dev->planes_live.load(),
+                     (long long)dev->tickets_live.load(), (long long)dev->mixers.load(),
+                     (long long)dev->frames_rendered.load());
+    if (n < 0 || (size_t)n >= capacity)
+        return fail(CGHIP_ERR_INVALID, "info buffer too small");
+    return CGHIP_OK;
+}
+
+int cghip_device_synchronize(cghip_device* dev)
+{
+    if (!dev)
+        return fail(CGHIP_ERR_INVALID, "dev is null");
+    CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
+    CGHIP_TRY_HIP(hipDeviceSynchronize());
+    return CGHIP_OK;
+}
+
+/* ---- pinned host staging */
+
+int cghip_host_alloc(cghip_device* dev, size_t bytes, int write, void** ptr, cghip_hostbuf** out)
+{
+    (void)write; /* the reference keeps separate read/write pools because PBOs are mapped one way; pinned memory is both */
+    if (!dev || !ptr || !out)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    void* p  = nullptr;
+    int   rc = dev->pinned_alloc(bytes, &p);
+    if (rc != CGHIP_OK)
+        return rc;
+    *out = new cghip_hostbuf{dev, p, bytes};
+    *ptr = p;
+    return CGHIP_OK;
+}
+
+int cghip_host_release(cghip_hostbuf* buf)
+{
+    if (!buf)
+        return CGHIP_OK;
+    buf->dev->pinned_free(buf->ptr, buf->bytes);
+    delete buf;
+    return CGHIP_OK;
+}
+
+/* ---- planes */
+
+static int plane_new(cghip_device* dev, int width, int height, int channels, int bits, cghip_plane** out)
+{
+    if (!dev || !out)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    if (width <= 0 || height <= 0 || channels < 1 || channels > 4 || (bits != 8 && bits != 16))
+        return fail(CGHIP_ERR_INVALID, "plane needs width,height > 0, 1..4 channels, 8 or 16 bits (device.cpp:196-197)");
+    cghip_plane* p = new cghip_plane();
+    p->dev = dev, p->width = width, p->height = height, p->channels = channels, p->bits = bits;
+    p->bytes = (size_t)width * height * channels * (bits / 8);
+    int rc   = dev->dev_alloc(p->bytes + 16, &p->dptr); /* +16: vector loads may touch past the last texel */
+    if (rc != CGHIP_OK) {
+        delete p;
+        return rc;
+    }
+    hipError_t e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        dev->dev_free(p->dptr, p->bytes + 16);
+        delete p;
+        return fail_hip(e, "hipEventCreateWithFlags");
+    }
+    dev->planes_live++;
+    *out = p;
+    return CGHIP_OK;
+}
+
+int cghip_plane_upload_async(cghip_device* dev, const void* src, int width, int height, int channels, int bits,
+                             cghip_plane** out)
+{
+    if (!src)
+        return fail(CGHIP_ERR_INVALID, "src is null");
+    cghip_plane* p  = nullptr;
+    int          rc = plane_new(dev, width, height, channels, bits, &p);
+    if (rc != CGHIP_OK)
+        return rc;
+    hipError_t e = hipSetDevice(dev->gpu);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(p->dptr, src, p->bytes, hipMemcpyHostToDevice, dev->upload_stream);
+    if (e == hipSuccess)
+        e = hipEventRecord(p->ready, dev->upload_stream);
+    if (e != hipSuccess) {
+        cghip_plane_release(p);
+        return fail_hip(e, "plane upload");
+    }
+    *out = p;
+    return CGHIP_OK;
+}
+
+int cghip_plane_retain(cghip_plane* plane)
+{
+    if (!plane)
+        return fail(CGHIP_ERR_INVALID, "plane is null");
+    plane->refs++;
+    return CGHIP_OK;
+}
+
+int cghip_plane_release(cghip_plane* plane)
+{
+    if (!plane)
+        return CGHIP_OK;
+    if (--plane->refs > 0)
+        return CGHIP_OK;
+    if (!plane->stub) {
+        /* the block goes back to the pool; whoever takes it next writes on a stream that is ordered after
+           every reader through the ready event chain, or after the ticket that retained the plane */
+        if (plane->ready) {
+            (void)hipEventSynchronize(plane->ready);
+            (void)hipEventDestroy(plane->ready);
+        }
+        plane->dev->dev_free(plane->dptr, plane->bytes + 16);
+        plane->dev->planes_live--;
+    }
+    delete plane;
+    return CGHIP_OK;
+}
+
+int cghip_plane_desc(const cghip_plane* plane, int* width, int* height, int* channels, int* bits, int* gpu_index)
+{
+    if (!plane)
+        return fail(CGHIP_ERR_INVALID, "plane is null");
+    if (width) *width = plane->width;
+    if (height) *height = plane->height;
+    if (channels) *channels = plane->channels;
+    if (bits) *bits = plane->bits;
+    if (gpu_index) *gpu_index = plane->dev ? plane->dev->gpu : -1;
+    return CGHIP_OK;
+}
+
+int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_plane** out)
+{
+    if (!dst_dev || !src || !out || src->stub)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    if (src->dev == dst_dev) { /* same GPU: share, like the reference's single GL context */
+        cghip_plane_retain(src);
+        *out = src;
+        return CGHIP_OK;
+    }
+    cghip_plane* p  = nullptr;
+    int          rc = plane_new(dst_dev, src->width, src->height, src->channels, src->bits, &p);
+    if (rc != CGHIP_OK)
+        return rc;
+    hipError_t e = hipSetDevice(dst_dev->gpu);
+    if (e == hipSuccess)
+        e = hipStreamWaitEvent(dst_dev->upload_stream, src->ready, 0);
+    if (e == hipSuccess)
+        e = hipMemcpyPeerAsync(p->dptr, dst_dev->gpu, src->dptr, src->dev->gpu, src->bytes, dst_dev->upload_stream);
+    if (e == hipSuccess)
+        e = hipEventRecord(p->ready, dst_dev->upload_stream);
+    if (e != hipSuccess) {
+        cghip_plane_release(p);
+        return fail_hip(e, "peer copy");
+    }
+    *out = p;
+    return CGHIP_OK;
+}
+
+/* planner tests: a plane descriptor with no device memory (never rendered) */
+int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_plane** out)
+{
+    if (!out)
+        return fail(CGHIP_ERR_INVALID, "out is null");
+    cghip_plane* p = new cghip_plane();
+    p->width = width, p->height = height, p->channels = channels, p->bits = bits;
+    p->bytes = (size_t)width * height * channels * (bits / 8);
+    p->stub  = true;
+    *out     = p;
+    return CGHIP_OK;
+}
+
+/* ---- mixer */
+
+int cghip_mixer_create(cghip_device* dev, int channel_id, cghip_mixer** out)
+{
+    if (!dev || !out)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
+    cghip_mixer* m = new cghip_mixer();
+    m->dev = dev, m->channel_id = channel_id;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete m;
+        return fail_hip(e, "hipStreamCreateWithFlags");
+    }
+    dev->mixers++;
+    *out = m;
+    return CGHIP_OK;
+}
+
+int cghip_mixer_destroy(cghip_mixer* mixer)
+{
+    if (!mixer)
+        return CGHIP_OK;
+    (void)hipSetDevice(mixer->dev->gpu);
+    (void)hipStreamSynchronize(mixer->stream);
+    (void)hipStreamDestroy(mixer->stream);
+    mixer->dev->mixers--;
+    delete mixer;
+    return CGHIP_OK;
+}
+
+static void ticket_free(cghip_ticket* t)
+{
+    cghip_device* dev = t->dev;
+    if (t->ev_done) {
+        (void)hipEventSynchronize(t->ev_done);
+        (void)hipEventDestroy(t->ev_done);
+    }
+    if (t->ev_start) (void)hipEventDestroy(t->ev_start);
+    if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
+    dev->dev_free(t->d_out, t->out_bytes);
+    dev->dev_free(t->d_ops, t->ops_bytes);
+    dev->pinned_free(t->h_ops, t->ops_bytes);
+    dev->pinned_free(t->h_out, t->out_bytes);
+    for (cghip_plane* p : t->planes)
+        cghip_plane_release(p);
+    dev->tickets_live--;
+    delete t;
+}
+
+int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, const cghip_surface* surfaces,
+                             int nsurfaces, const cghip_draw* draws, int ndraws, unsigned flags, cghip_ticket** out)
+{
+    if (!mixer || !out)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    frame_plan plan;
+    int        rc = plan_frame(format, surfaces, nsurfaces, draws, ndraws, &plan);
+    if (rc != CGHIP_OK)
+        return rc;
+    for (cghip_plane* p : plan.planes)
+        if (p->stub || p->dev != mixer->dev)
+            return fail(CGHIP_ERR_INVALID, "plane lives on another device: route it with cghip_plane_peer_copy_async");
+
+    cghip_device* dev = mixer->dev;
+    CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
+    cghip_ticket* t = new cghip_ticket();
+    t->dev = dev, t->stream = mixer->stream;
+    dev->tickets_live++;
+    t->out_bytes = (size_t)format->width * format->height * 4 * (format->bits / 8);
+    t->ops_bytes = std::max<size_t>(plan.ops.size(), 1) * sizeof(KOp);
+#define T_TRY(expr)                                                                                                    \
+    do {                                                                                                               \
+        int rc__ = (expr);                                                                                             \
+        if (rc__ != CGHIP_OK) {                                                                                        \
+            ticket_free(t);                                                                                            \
+            return rc__;                                                                                               \
+        }                                                                                                              \
+    } while (0)
+#define T_HIP(expr)                                                                                                    \
+    do {                                                                                                               \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess) {                                                                                       \
+            ticket_free(t);                                                                                            \
+            return fail_hip(e__, #expr);                                                                               \
+        }                                                                                                              \
+    } while (0)
+    T_TRY(dev->dev_alloc(t->out_bytes, &t->d_out));
+    T_TRY(dev->dev_alloc(t->ops_bytes, &t->d_ops));
+    T_TRY(dev->pinned_alloc(t->ops_bytes, &t->h_ops));
+    T_HIP(hipEventCreate(&t->ev_start));
+    T_HIP(hipEventCreate(&t->ev_stop));
+    T_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+
+    /* the frame keeps its source planes alive and waits for their uploads (device.cpp:242-262 futures) */
+    for (cghip_plane* p : plan.planes) {
+        cghip_plane_retain(p);
+        t->planes.push_back(p);
+        T_HIP(hipStreamWaitEvent(t->stream, p->ready, 0));
+    }
+    if (!plan.ops.empty()) {
+        std::memcpy(t->h_ops, plan.ops.data(), plan.ops.size() * sizeof(KOp));
+        T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, t->stream));
+    }
+    T_HIP(hipEventRecord(t->ev_start, t->stream));
+    /* empty scene: the kernel with zero ops writes the all-zero frame (image_mixer.cpp:89-92) */
+    T_HIP(cghip_launch_composite((const KOp*)t->d_ops, (int)plan.ops.size(), t->d_out, format->width, format->height,
+                                 format->bits, format->field_mode, plan.full ? 1 : 0, t->stream));
+    t->launches = 1;
+    T_HIP(hipEventRecord(t->ev_stop, t->stream));
+    if (flags & CGHIP_RENDER_READBACK) {
+        T_TRY(dev->pinned_alloc(t->out_bytes, &t->h_out));
+        T_HIP(hipMemcpyAsync(t->h_out, t->d_out, t->out_bytes, hipMemcpyDeviceToHost, t->stream));
+    }
+    T_HIP(hipEventRecord(t->ev_done, t->stream));
+#undef T_TRY
+#undef T_HIP
+    dev->frames_rendered++;
+    *out = t;
+    return CGHIP_OK;
+}
+
+int cghip_ticket_wait(cghip_ticket* ticket, const uint8_t** data, size_t* size)
+{
+    if (!ticket)
+        return fail(CGHIP_ERR_INVALID, "ticket is null");
+    CGHIP_TRY_HIP(hipEventSynchronize(ticket->ev_done));
+    if (data) {
+        if (!ticket->h_out)
+            return fail(CGHIP_ERR_INVALID, "frame was rendered without CGHIP_RENDER_READBACK");
+        *data = (const uint8_t*)ticket->h_out;
+    }
+    if (size)
+        *size = ticket->out_bytes;
+    return CGHIP_OK;
+}
+
+int cghip_ticket_device_ptr(cghip_ticket* ticket, const void** device_ptr, size_t* size)
+{
+    if (!ticket || !device_ptr)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    *device_ptr = ticket->d_out;
+    if (size)
+        *size = ticket->out_bytes;
+    return CGHIP_OK;
+}
+
+int cghip_ticket_kernel_ms(cghip_ticket* ticket, float* ms, int* launches)
+{
+    if (!ticket || !ms)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    CGHIP_TRY_HIP(hipEventSynchronize(ticket->ev_stop));
+    CGHIP_TRY_HIP(hipEventElapsedTime(ms, ticket->ev_start, ticket->ev_stop));
+    if (launches)
+        *launches = ticket->launches;
+    return CGHIP_OK;
+}
+
+int cghip_ticket_release(cghip_ticket* ticket)
+{
+    if (!ticket)
+        return CGHIP_OK;
+    ticket_free(ticket);
+    return CGHIP_OK;
+}
+
+} /* extern "C" */
