@@ -253,5 +253,5 @@ class RefMixer:
         self.ndraws = n
         if log:
             p = self.L.ref_mixer_log(self.h)
-            self.draw_log = [p[i] for i in range(self.L.ref_mixer_log_size(self.h))]
+            self.draw_log = [Draw.from_buffer_copy(p[i]) for i in range(self.L.ref_mixer_log_size(self.h))]
         return out

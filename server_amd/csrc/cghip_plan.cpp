@@ -202,6 +202,17 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
         return 0;
     if (!d.geometry_is_quad) /* :378,413 */
         return 0;
+    /* Every parallelogram gets q = 2 at all four corners (the diagonals bisect each other, :359-362), so the
+       shader's TexCoord.st / TexCoord.q is an exact division by a constant: fold it into the map here and
+       keep the per-pixel divide for genuinely projective quads only. */
+    if ((float)q[0].q == (float)q[1].q && (float)q[1].q == (float)q[2].q && (float)q[2].q == (float)q[3].q &&
+        (float)q[0].q != 0.0f && (float)q[0].q != 1.0f) {
+        for (int i = 0; i < 4; ++i) {
+            q[i].s = (double)((float)q[i].s / (float)q[i].q);
+            q[i].t = (double)((float)q[i].t / (float)q[i].q);
+            q[i].q = 1.0;
+        }
+    }
 
     const cghip_transform& t = d.transform;
     const int              W = fmt.width, H = fmt.height;

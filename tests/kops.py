@@ -1,0 +1,51 @@
+"""ctypes mirror of server_amd/csrc/cghip_kops.h (KOp), for planner introspection in tests."""
+import ctypes as C
+
+
+class KPlane(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("channels", C.c_int32), ("bits", C.c_int32),
+                ("fw", C.c_float), ("fh", C.c_float)]
+
+
+class KTri(C.Structure):
+    _fields_ = [("e", (C.c_double * 3) * 3), ("a", (C.c_double * 3) * 3)]
+
+
+class KOp(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("flags", C.c_uint32), ("dst", C.c_int32), ("src_surface", C.c_int32),
+        ("local_key", C.c_int32), ("layer_key", C.c_int32), ("pixel_format", C.c_int32), ("blend_mode", C.c_int32),
+        ("nplanes", C.c_int32), ("ntri", C.c_int32),
+        ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
+        ("unit_dx", C.c_int32), ("unit_dy", C.c_int32),
+        ("opacity", C.c_float),
+        ("lv_min_input", C.c_float), ("lv_inv_range", C.c_float), ("lv_inv_gamma", C.c_float),
+        ("lv_min_output", C.c_float), ("lv_max_output", C.c_float),
+        ("brt", C.c_float), ("sat", C.c_float), ("con", C.c_float),
+        ("ch_target_hue", C.c_float), ("ch_hue_width", C.c_float), ("ch_min_saturation", C.c_float),
+        ("ch_min_brightness", C.c_float), ("ch_softness", C.c_float), ("ch_spill", C.c_float),
+        ("ch_spill_saturation", C.c_float),
+        ("pad_", C.c_float * 3),
+        ("planes", KPlane * 4), ("tri", KTri * 2),
+    ]
+
+
+KOP_CLEAR, KOP_DRAW_PLANES, KOP_DRAW_SURFACE = 0, 1, 2
+KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE = \
+    [1 << i for i in range(10)]
+KS_RGBA0, KS_RGBA1, KS_RGBA2, KS_KEY0, KS_KEY1 = range(5)
+
+
+def plan(fmt, surfaces, draws):
+    """Run the product's host planner on a draw list (no GPU). Returns (list[KOp], full)."""
+    import server_amd as A
+    L = A.lib()
+    assert L.cghip_debug_kop_size() == C.sizeof(KOp), (L.cghip_debug_kop_size(), C.sizeof(KOp))
+    sa = (A.Surface * len(surfaces))(*[A.Surface(c, 0) for c in surfaces])
+    da = (A.Draw * max(1, len(draws)))(*draws)
+    out = (KOp * 512)()
+    n, full = C.c_int(0), C.c_int(0)
+    rc = L.cghip_debug_plan(C.byref(fmt), sa, len(surfaces), da, len(draws), out, 512, C.byref(n), C.byref(full))
+    if rc != 0:
+        raise A.CGHIPError(rc, L.cghip_last_error().decode())
+    return [out[i] for i in range(n.value)], bool(full.value)

@@ -1,0 +1,244 @@
+"""CPU suite: the product's HOST logic (C++ push/visit/pop/flatten in server_amd/host/, planner in
+server_amd/csrc/cghip_plan.cpp) against the oracle's independent restatement (oracle/ref_scene.c), with no GPU.
+
+Both sides restate image_mixer.cpp:104-299 and image_kernel.cpp:134-375; the oracle's version is pinned through the
+llvmpipe goldens (test_oracle_golden.py), so agreement here pins the product's draw order, temporaries, uniforms
+and quad math.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import kops as K
+import scenes as S
+import server_amd as A
+from oracle import oracle as O
+
+SCENES = [s for s in S.small_scenes() + S.blend_mode_scenes() if s["ops"]]
+
+
+def product_plan(sc):
+    m = A.Mixer(channel_id=1, gpu=-2)  # dry run: no device needed
+    try:
+        S.feed_product(m, sc, via_factory=False)
+        draws, surfaces = m.flatten(sc["width"], sc["height"], sc["square_width"], sc["square_height"], sc["bits"])
+        fmt = A.Format(sc["width"], sc["height"], sc["square_width"], sc["square_height"], sc["bits"], 0)
+        ops, full = K.plan(fmt, surfaces, draws)
+        return draws, surfaces, ops, full
+    finally:
+        m.close()
+
+
+def oracle_log(sc):
+    m = O.RefMixer("cpu")
+    try:
+        for op in sc["ops"]:
+            if op[0] == "push":
+                kw = {S.TRANSFORM_RENAME_ORACLE.get(k, k): v for k, v in op[1].items()}
+                m.push(O.default_transform(**kw))
+            elif op[0] == "visit":
+                m.visit(O.make_frame(op[1]["fmt"], S.materialize(op[1]), coords=op[1].get("coords")))
+            else:
+                m.pop()
+        m.render(sc["width"], sc["height"], sc["square_width"], sc["square_height"], sc["bits"], log=True)
+        return m.draw_log
+    finally:
+        m.close()
+
+
+def executed_mode(mode):  # shader.frag:389-421 aliasing
+    return 0 if (mode == 12 or mode >= 29 or mode < 0) else mode
+
+
+@pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
+def test_planner_agrees_with_oracle_draw_list(sc):
+    _draws, _surf, ops, _full = product_plan(sc)
+    log = oracle_log(sc)
+    kd = [o for o in ops if o.kind != K.KOP_CLEAR]
+    # the oracle logs every draw that reaches GL; the planner additionally drops draws whose pixel box is empty
+    W, H = sc["width"], sc["height"]
+    assert len(kd) <= len(log)
+    it = iter(log)
+    for o in kd:
+        for d in it:
+            if same_draw(o, d):
+                break
+        else:
+            pytest.fail("planner op without a matching oracle draw, in order")
+        check_uniforms(o, d)
+        check_geometry(o, d, W, H)
+
+
+def same_draw(o, d):
+    return (o.pixel_format == d.pixel_format and executed_mode(d.blend_mode) == o.blend_mode and
+            bool(o.flags & K.KF_ADDITIVE) == (d.keyer == 1) and abs(o.opacity - d.opacity) < 1e-7 and
+            (o.local_key >= 0) == bool(d.has_local_key) and (o.layer_key >= 0) == bool(d.has_layer_key))
+
+
+def check_uniforms(o, d):
+    assert bool(o.flags & K.KF_INVERT) == bool(d.invert)
+    assert bool(o.flags & K.KF_LEVELS) == bool(d.levels)
+    assert bool(o.flags & K.KF_CSB) == bool(d.csb)
+    assert bool(o.flags & K.KF_CHROMA) == bool(d.chroma)
+    if o.kind == K.KOP_DRAW_PLANES:
+        assert bool(o.flags & K.KF_IS_HD) == bool(d.is_hd)
+    if d.levels:
+        assert o.lv_min_input == d.min_input and o.lv_min_output == d.min_output and o.lv_max_output == d.max_output
+        assert o.lv_inv_range == pytest.approx(1.0 / (np.float32(d.max_input) - np.float32(d.min_input)), rel=1e-6)
+        assert o.lv_inv_gamma == pytest.approx(1.0 / d.gamma, rel=1e-6)
+    if d.csb:
+        assert (o.brt, o.sat, o.con) == (d.brt, d.sat, d.con)
+    if d.chroma:
+        assert bool(o.flags & K.KF_CHROMA_MASK) == bool(d.chroma_show_mask)
+        for a, b in (("ch_target_hue", "chroma_target_hue"), ("ch_hue_width", "chroma_hue_width"),
+                     ("ch_min_saturation", "chroma_min_saturation"), ("ch_min_brightness", "chroma_min_brightness"),
+                     ("ch_softness", "chroma_softness"), ("ch_spill", "chroma_spill_suppress"),
+                     ("ch_spill_saturation", "chroma_spill_suppress_saturation")):
+            assert getattr(o, a) == getattr(d, b), a
+
+
+def check_geometry(o, d, W, H):
+    # varyings of both triangles must reproduce the oracle's transformed quad at its own vertices
+    tri_idx = ((0, 1, 2), (0, 2, 3))
+    ntri_used = 0
+    for t, idx in enumerate(tri_idx):
+        xs = [np.float32(d.coords[i].vertex_x) for i in idx]
+        ys = [np.float32(d.coords[i].vertex_y) for i in idx]
+        area = (xs[1] - xs[0]) * (ys[2] - ys[0]) - (ys[1] - ys[0]) * (xs[2] - xs[0])
+        if abs(area) < 1e-9:
+            continue
+        tri = o.tri[ntri_used]
+        ntri_used += 1
+        for i in idx:
+            c = d.coords[i]
+            px = float(np.float32(c.vertex_x)) * W - 0.5
+            py = float(np.float32(c.vertex_y)) * H - 0.5
+            got = [tri.a[j][0] + tri.a[j][1] * px + tri.a[j][2] * py for j in range(3)]
+            # the planner folds a uniform q (2.0 for every parallelogram) into s,t: compare after the divide
+            assert got[0] / got[2] == pytest.approx(c.texture_x / c.texture_q, abs=2e-5), (t, i, "s")
+            assert got[1] / got[2] == pytest.approx(c.texture_y / c.texture_q, abs=2e-5), (t, i, "t")
+            if o.flags & K.KF_PROJECTIVE:
+                assert got[2] == pytest.approx(float(np.float32(c.texture_q)), abs=2e-5), (t, i, "q")
+    # pixel box: inside the frame and inside the oracle's scissor
+    assert 0 <= o.x0 < o.x1 <= W and 0 <= o.y0 < o.y1 <= H
+    if d.scissor:
+        assert o.x0 >= d.sc_x and o.y0 >= d.sc_y and o.x1 <= d.sc_x + d.sc_w and o.y1 <= d.sc_y + d.sc_h
+
+
+def test_transform_compose_matches_oracle():
+    """image_transform::operator*= (frame_transform.cpp:53-108): C++ host vs oracle C, on seeded random transforms,
+    observed through the flattened draw's transform."""
+    rng = np.random.default_rng(7)
+    for _ in range(25):
+        def rnd():
+            return dict(opacity=rng.uniform(.2, 1), contrast=rng.uniform(.5, 1.5), brightness=rng.uniform(.5, 1.5),
+                        saturation=rng.uniform(.5, 1.5), anchor=list(rng.uniform(-.2, .2, 2)),
+                        fill_translation=list(rng.uniform(-.3, .3, 2)), fill_scale=list(rng.uniform(.5, 1.5, 2)),
+                        clip_translation=list(rng.uniform(0, .2, 2)), clip_scale=list(rng.uniform(.5, 1, 2)),
+                        angle=rng.uniform(-1, 1), crop_ul=list(rng.uniform(0, .2, 2)), crop_lr=list(rng.uniform(.7, 1, 2)),
+                        pers_ul=list(rng.uniform(0, .1, 2)), pers_ur=[rng.uniform(.9, 1), rng.uniform(0, .1)],
+                        pers_lr=list(rng.uniform(.9, 1, 2)), pers_ll=[rng.uniform(0, .1), rng.uniform(.9, 1)],
+                        levels_min_input=rng.uniform(0, .2), levels_max_input=rng.uniform(.8, 1),
+                        levels_gamma=rng.uniform(.5, 2), levels_min_output=rng.uniform(0, .2),
+                        levels_max_output=rng.uniform(.8, 1), chroma_enable=int(rng.integers(0, 2)),
+                        chroma_target_hue=rng.uniform(0, 360), chroma_hue_width=rng.uniform(0, .3),
+                        chroma_min_saturation=rng.uniform(0, .5), chroma_min_brightness=rng.uniform(0, .5),
+                        chroma_softness=rng.uniform(0, .5), chroma_spill_suppress=rng.uniform(0, 90),
+                        chroma_spill_suppress_saturation=rng.uniform(0, 1), invert=int(rng.integers(0, 2)),
+                        blend_mode=int(rng.integers(0, 30)))
+        a, b, c = rnd(), rnd(), rnd()
+        a["layer_depth"] = 1
+        m = A.Mixer(1, -2)
+        for t in (a, b, c):
+            m.push(A.default_transform(**t))
+        m.visit("bgra", [np.zeros((4, 4, 4), np.uint8)], via_factory=False)
+        draws, _ = m.flatten(64, 64)
+        m.close()
+        got = draws[0].transform  # the item draw (a blend-mode layer appends its composite draw)
+        want = O.default_transform()
+        for t in (a, b, c):
+            kw = {S.TRANSFORM_RENAME_ORACLE.get(k, k): v for k, v in t.items()}
+            O.lib().ref_transform_compose(C.byref(want), C.byref(O.default_transform(**kw)))
+        for name, _ in A.Transform._fields_:
+            if name == "reserved_":
+                continue
+            g = getattr(got, name)
+            w = getattr(want, S.TRANSFORM_RENAME_ORACLE.get(name, name))
+            if isinstance(g, C.Array):
+                assert list(g) == pytest.approx(list(w), rel=1e-12, abs=1e-15), name
+            else:
+                assert g == pytest.approx(w, rel=1e-12, abs=1e-15), name
+
+
+def test_surface_temporaries_follow_the_reference_renderer():
+    # key layer then fill: one 1-channel temporary, consumed as LAYER key by the next layer (image_mixer.cpp:153)
+    sc = [s for s in S.small_scenes() if s["name"] == "key_then_fill_same_layer_depth"][0]
+    draws, surfaces, ops, full = product_plan(sc)
+    assert surfaces == [4, 1] and not full
+    assert draws[1].target == 1 and draws[2].layer_key == 1 and draws[2].local_key == -1
+    # local key inside one layer is consumed by the first fill as LOCAL key (image_mixer.cpp:200)
+    sc = [s for s in S.small_scenes() if s["name"] == "local_key_and_fill_in_one_layer"][0]
+    draws, surfaces, ops, full = product_plan(sc)
+    assert draws[2].local_key == 1 and draws[2].layer_key == -1
+    # MIX: two additive draws into a 4-channel temporary, flushed onto the target with a surface draw (:150,:184-195)
+    sc = [s for s in S.small_scenes() if s["name"] == "mix_transition"][0]
+    draws, surfaces, ops, full = product_plan(sc)
+    assert surfaces == [4, 4] and full
+    assert [d.keyer for d in draws[1:3]] == [1, 1] and draws[3].source_surface == 1 and draws[3].target == 0
+    # non-normal blend layer: items -> layer temporary, then composited with the layer's mode (:127-139)
+    sc = [s for s in S.blend_mode_scenes() if s["name"] == "blend_screen"][0]
+    draws, surfaces, ops, full = product_plan(sc)
+    assert surfaces == [4, 4] and draws[1].target == 1 and draws[1].blend_mode == 0
+    assert draws[2].source_surface == 1 and draws[2].target == 0 and draws[2].blend_mode == A.BLEND["screen"]
+
+
+def test_fast_path_classification():
+    full_frame = S.scene("f", 96, 64, [S.layer(S.ycbcr(96, 64, "422", "video", 1), opacity=0.5)])
+    _d, _s, ops, _f = product_plan(full_frame)
+    o = [x for x in ops if x.kind == K.KOP_DRAW_PLANES][0]
+    assert o.flags & K.KF_RECT and o.flags & K.KF_UNIT_SCALE and (o.unit_dx, o.unit_dy) == (0, 0)
+    assert (o.x0, o.y0, o.x1, o.y1) == (0, 0, 96, 64)
+    scaled = S.scene("s", 96, 64, [S.layer(S.bgra(96, 64), fill_scale=[0.5, 0.5])])
+    o = [x for x in product_plan(scaled)[2] if x.kind == K.KOP_DRAW_PLANES][0]
+    assert o.flags & K.KF_RECT and not (o.flags & K.KF_UNIT_SCALE) and (o.x1, o.y1) == (48, 32)
+    rotated = S.scene("r", 96, 64, [S.layer(S.bgra(96, 64), angle=0.2)])
+    o = [x for x in product_plan(rotated)[2] if x.kind == K.KOP_DRAW_PLANES][0]
+    assert not (o.flags & K.KF_RECT)
+    cropped = S.scene("c", 96, 64, [S.layer(S.bgra(96, 64), crop_ul=[0.25, 0.25], crop_lr=[0.75, 0.75])])
+    o = [x for x in product_plan(cropped)[2] if x.kind == K.KOP_DRAW_PLANES][0]
+    assert o.flags & K.KF_UNIT_SCALE and (o.x0, o.y0, o.x1, o.y1) == (24, 16, 72, 48)
+
+
+def test_planner_rejects_bad_input():
+    fmt = A.Format(64, 64, 64, 64, 8, 0)
+    with pytest.raises(A.CGHIPError):
+        K.plan(A.Format(0, 64, 64, 64, 8, 0), [4], [])
+    with pytest.raises(A.CGHIPError):
+        K.plan(A.Format(64, 64, 64, 64, 12, 0), [4], [])
+    with pytest.raises(A.CGHIPError):
+        K.plan(fmt, [1], [])  # surface 0 must be RGBA
+    d = A.Draw()
+    d.target = 5
+    with pytest.raises(A.CGHIPError):
+        K.plan(fmt, [4], [d])
+    ops, full = K.plan(fmt, [4], [])
+    assert ops == [] and not full  # empty scene plans to zero ops
+
+
+def test_visit_without_open_layer_is_an_error():
+    m = A.Mixer(1, -2)
+    m.push(A.default_transform())  # layer_depth 0: the reference would dereference an empty layer stack
+    with pytest.raises(A.CGHIPError):
+        m.visit("bgra", [np.zeros((2, 2, 4), np.uint8)], via_factory=False)
+    m.close()
+
+
+def test_dry_run_mixer_cannot_render():
+    m = A.Mixer(1, -2)
+    m.push(A.default_transform(layer_depth=1))
+    m.visit("bgra", [np.zeros((2, 2, 4), np.uint8)], via_factory=False)
+    m.pop()
+    with pytest.raises(A.CGHIPError):
+        m.render(8, 8)
+    m.close()
