@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- composited frames/s of the HIP image mixer on BASELINE.json's headline configuration.
+
+A step = one pass of the hot path: one channel composites one frame of the workload (default: configs[2], the
+2160p50 16-layer ycbcr 4:2:2 16-bit stack with key layers, chroma key and levels, BGRA16 out) through the same
+calls core::mixer makes (push / visit / pop / render, core/mixer/mixer.cpp:62-92). Source planes are uploaded once
+and stay resident in HBM (a still frame is re-visited every tick without re-upload in the reference too); the
+frame stays in HBM as well (no readback) so `value` is the compositor's own rate. The PCIe-inclusive rate is
+reported separately as `end_to_end_fps` (pinned H2D of every plane + D2H of the frame each step).
+
+Multi-GPU: channels shard by GPU with no data-path collective: rank r drives its own channel on GPU
+LOCAL_RANK; value = N frames per step-time (weak scaling). torch.distributed is only the barrier + max-reduce.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    "config3_16bit": lambda S: S.config3(bits=16),
+    "config3_8bit": lambda S: S.config3(bits=8),
+    "config2": lambda S: S.config2(),
+    "config1": lambda S: S.config1(),
+    "config4": lambda S: S.config4(),
+}
+
+
+def dist_setup(n_gpus):
+    """Returns (rank, world, local_rank, barrier, allreduce_max). Single process when WORLD_SIZE is unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return rank, world, local_rank, (lambda: None), (lambda x: x)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    backend = os.environ.get("CGHIP_DIST_BACKEND", "nccl" if use_gpu else "gloo")
+    try:
+        dist.init_process_group(backend=backend)
+    except Exception:
+        backend = "gloo"
+        dist.init_process_group(backend=backend)
+    dev = torch.device("cuda", local_rank) if (backend == "nccl") else torch.device("cpu")
+
+    def barrier():
+        dist.barrier()
+
+    def allreduce_max(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    return rank, world, local_rank, barrier, allreduce_max
+
+
+def device_sync():
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+class Channel:
+    """One video channel: a HIP image mixer plus its resident source frames."""
+
+    def __init__(self, A, S, scene, gpu, channel_id):
+        self.A, self.S, self.scene = A, S, scene
+        self.mixer = A.Mixer(channel_id=channel_id, gpu=gpu)
+        self.ops = []
+        self.frames = []
+        for op in scene["ops"]:
+            if op[0] == "push":
+                self.ops.append(("push", A.default_transform(**op[1])))
+            elif op[0] == "visit":
+                spec = op[1]
+                fr = self.mixer.create_frame(spec["fmt"], S.materialize(spec), spec.get("coords"))
+                self.frames.append(fr)
+                self.ops.append(("visit", fr))
+            else:
+                self.ops.append(("pop", None))
+
+    def submit(self, readback=False):
+        m = self.mixer
+        for kind, arg in self.ops:
+            if kind == "push":
+                m.push(arg)
+            elif kind == "visit":
+                m.visit_frame(arg)
+            else:
+                m.pop()
+        sc = self.scene
+        return m.render_async(sc["width"], sc["height"], sc["square_width"], sc["square_height"], sc["bits"],
+                              sc["field_mode"], readback=readback)
+
+    def close(self):
+        for f in self.frames:
+            self.mixer.destroy_frame(f)
+        self.mixer.close()
+
+
+def run_steps(ch, steps, in_flight=2):
+    """Issue `steps` frames keeping `in_flight` in the pipeline (the reference keeps 1-2, mixer.cpp:75-91).
+    Returns the list of per-frame kernel durations (ms, hipEvents on the channel's compute stream)."""
+    pend, kernel_ms = [], []
+    for _ in range(steps):
+        pend.append(ch.submit(readback=False))
+        if len(pend) > in_flight:
+            ch.mixer.get(pend.pop(0), want_output=False)
+            kernel_ms.append(ch.mixer.last_kernel_ms)
+    while pend:
+        ch.mixer.get(pend.pop(0), want_output=False)
+        kernel_ms.append(ch.mixer.last_kernel_ms)
+    return kernel_ms
+
+
+def end_to_end_fps(A, S, scene, gpu, steps):
+    """PCIe-inclusive: every step re-creates every source frame (pinned H2D) and reads the frame back (D2H)."""
+    m = A.Mixer(channel_id=99, gpu=gpu)
+    cache = {}
+    S.run_product(scene, mixer=m, planes_cache=cache)  # warm pools
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        S.run_product(scene, mixer=m, planes_cache=cache)
+    dt = time.perf_counter() - t0
+    m.close()
+    return steps / dt
+
+
+def cpu_baseline(S, scene, budget_s=12.0):
+    """The oracle (scalar C restatement of the reference mixer, OpenMP over rows) on this box's host cores."""
+    from oracle import oracle as O
+    cores = min(16, os.cpu_count() or 1)  # the GPU box gives one GPU's share of 16 cores
+    O.lib().cpuref_set_threads(cores)
+    cache = {}
+    for op in scene["ops"]:  # synthesise the inputs outside the timed region
+        if op[0] == "visit":
+            S._planes(op[1], cache)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        S.run_oracle(scene, "cpu", cache)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 3:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d full frame(s) of the same workload (%s), includes texture upload copies and readback copy"
+                      % (n, scene["name"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config3_16bit", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank, barrier, allreduce_max = dist_setup(args.gpus)
+    import scenes as S
+    import server_amd as A
+
+    ndev = A.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the mixer has no CPU fallback)")
+    gpu = local_rank % ndev
+    scene = WORKLOADS[args.workload](S)
+    ch = Channel(A, S, scene, gpu, channel_id=rank + 1)
+
+    run_steps(ch, max(1, args.warmup))
+    device_sync()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = run_steps(ch, args.steps)
+    device_sync()
+    barrier()
+    dt = allreduce_max(time.perf_counter() - t0)
+
+    alg_bytes = S.algorithmic_bytes(scene)
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        e2e = end_to_end_fps(A, S, scene, gpu, 3)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(S, scene)
+    ch.close()
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "composited frames/s per GPU (2160p, 16 layers) + % of HBM roofline",
+            "value": world * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d layers, %d-bit out" % (
+                scene["name"], scene["width"], scene["height"],
+                sum(1 for o in scene["ops"] if o[0] == "visit"), scene["bits"]),
+                "channels_per_gpu": 1, "frames_in_flight": 2, "parallelism": "channel-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "cghip_composite", "avg_kernel_ms": avg_kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu,
+            "end_to_end_fps": e2e,
+        }
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

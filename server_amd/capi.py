@@ -157,6 +157,12 @@ def host():
                                            C.POINTER(C.c_float)]
         Hh.cghost_mixer_flatten.argtypes = [C.c_void_p, C.POINTER(Format), C.POINTER(Draw), C.c_int,
                                             C.POINTER(C.c_int), C.POINTER(Surface), C.POINTER(C.c_int)]
+        Hh.cghost_frame_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(HostPlane), C.POINTER(Coord), C.c_int,
+                                           C.POINTER(C.c_void_p)]
+        Hh.cghost_frame_destroy.argtypes = [C.c_void_p]
+        Hh.cghost_mixer_visit_frame.argtypes = [C.c_void_p, C.c_void_p]
+        Hh.cghost_mixer_render_async.argtypes = [C.c_void_p, C.POINTER(Format), C.c_int, C.POINTER(C.c_void_p)]
+        Hh.cghost_future_get.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
         Hh.cghost_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         Hh.cghost_device_gc.argtypes = [C.c_int]
         _host = Hh
@@ -249,6 +255,56 @@ class Mixer:
             v = list(c) + ([0.0, 1.0] if len(c) == 4 else [])
             (cc[i].vertex_x, cc[i].vertex_y, cc[i].texture_x, cc[i].texture_y, cc[i].texture_r, cc[i].texture_q) = v
         check_host(self.H.cghost_mixer_visit(self.h, pf, len(planes), hp, cc, len(cs), 1 if via_factory else 0))
+
+    def _host_planes(self, planes, keep):
+        hp = (HostPlane * max(1, len(planes)))()
+        for i, p in enumerate(planes):
+            a = np.ascontiguousarray(p)
+            keep.append(a)
+            hp[i].height, hp[i].width = a.shape[0], a.shape[1]
+            hp[i].stride = 1 if a.ndim == 2 else a.shape[2]
+            hp[i].bits = 8 * a.dtype.itemsize
+            hp[i].data = a.ctypes.data
+        return hp
+
+    def create_frame(self, fmt, planes, coords=None):
+        """create_frame + fill + commit: returns a handle to a const_frame whose planes stay resident in HBM."""
+        pf = PF[fmt] if isinstance(fmt, str) else int(fmt)
+        keep = []
+        hp = self._host_planes(planes, keep)
+        cc = (Coord * 4)()
+        n = 0
+        if coords is not None:
+            n = 4
+            for i, c in enumerate(coords):
+                v = list(c) + ([0.0, 1.0] if len(c) == 4 else [])
+                (cc[i].vertex_x, cc[i].vertex_y, cc[i].texture_x, cc[i].texture_y, cc[i].texture_r, cc[i].texture_q) = v
+        h = C.c_void_p()
+        check_host(self.H.cghost_frame_create(self.h, pf, len(planes), hp, cc, n, C.byref(h)))
+        return h
+
+    def destroy_frame(self, frame):
+        self.H.cghost_frame_destroy(frame)
+
+    def visit_frame(self, frame):
+        check_host(self.H.cghost_mixer_visit_frame(self.h, frame))
+
+    def render_async(self, width, height, square_width=None, square_height=None, bits=8, field_mode=0,
+                     readback=True):
+        fmt = self._format(width, height, square_width, square_height, bits, field_mode)
+        h = C.c_void_p()
+        check_host(self.H.cghost_mixer_render_async(self.h, C.byref(fmt), 1 if readback else 0, C.byref(h)))
+        shape = (height, width, 4)
+        return (h, shape, np.uint8 if bits == 8 else np.uint16, readback)
+
+    def get(self, pending, want_output=True):
+        h, shape, dt, readback = pending
+        out = np.zeros(shape, dtype=dt) if (readback and want_output) else None
+        ms = C.c_float(0.0)
+        check_host(self.H.cghost_future_get(h, out.ctypes.data if out is not None else None,
+                                            out.nbytes if out is not None else 0, C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return out
 
     def pop(self):
         check_host(self.H.cghost_mixer_pop(self.h))

@@ -155,6 +155,45 @@ int cghost_mixer_visit(void* h, int pixel_format, int nplanes, const cghost_plan
     });
 }
 
+/* A still frame that stays resident in HBM and is re-visited every tick without a new upload, the way a paused
+ * clip or an image producer's frame is (modules/image/producer/image_producer.cpp:89-100 creates it once). */
+int cghost_frame_create(void* h, int pixel_format, int nplanes, const cghost_plane* planes, const cghip_coord* coords,
+                        int ncoords, void** out)
+{
+    return guarded([&] {
+        auto&                   mixer = *static_cast<host_mixer*>(h)->mixer;
+        core::pixel_format_desc desc(static_cast<core::pixel_format>(pixel_format));
+        for (int n = 0; n < nplanes; ++n)
+            desc.planes.emplace_back(planes[n].width, planes[n].height, planes[n].stride, planes[n].bits);
+        auto frame = mixer.create_frame(nullptr, desc);
+        for (int n = 0; n < nplanes; ++n)
+            std::memcpy(frame.image_data(static_cast<std::size_t>(n)).data(), planes[n].data,
+                        static_cast<std::size_t>(desc.planes[static_cast<std::size_t>(n)].size));
+        if (ncoords == 4) {
+            std::vector<core::frame_geometry::coord> g;
+            for (int i = 0; i < 4; ++i) {
+                core::frame_geometry::coord c(coords[i].vertex_x, coords[i].vertex_y, coords[i].texture_x, coords[i].texture_y);
+                c.texture_r = coords[i].texture_r;
+                c.texture_q = coords[i].texture_q;
+                g.push_back(c);
+            }
+            frame.geometry() = core::frame_geometry(core::frame_geometry::geometry_type::quad, g);
+        }
+        *out = new core::const_frame(std::move(frame));
+    });
+}
+
+int cghost_frame_destroy(void* frame)
+{
+    delete static_cast<core::const_frame*>(frame);
+    return 0;
+}
+
+int cghost_mixer_visit_frame(void* h, void* frame)
+{
+    return guarded([&] { static_cast<host_mixer*>(h)->mixer->visit(*static_cast<core::const_frame*>(frame)); });
+}
+
 int cghost_mixer_pop(void* h)
 {
     return guarded([&] { static_cast<host_mixer*>(h)->mixer->pop(); });
@@ -183,6 +222,39 @@ int cghost_mixer_render(void* h, const cghip_format* f, void* out, size_t capaci
         }
         if (kernel_ms)
             *kernel_ms = mixer.last_kernel_ms();
+    });
+}
+
+/* operator() without the get(): the deferred future is returned as a handle (core/mixer/mixer.cpp:70-91 keeps it
+ * in a queue and calls get() one tick later). */
+struct pending_frame
+{
+    std::future<array<const std::uint8_t>> fut;
+    hip::image_mixer*                      mixer;
+    bool                                   readback;
+};
+
+int cghost_mixer_render_async(void* h, const cghip_format* f, int readback, void** out)
+{
+    return guarded([&] {
+        auto& mixer = *static_cast<host_mixer*>(h)->mixer;
+        mixer.set_readback(readback != 0);
+        *out = new pending_frame{mixer(to_desc(f)), &mixer, readback != 0};
+    });
+}
+
+int cghost_future_get(void* pending, void* out, size_t capacity, float* kernel_ms)
+{
+    std::unique_ptr<pending_frame> p(static_cast<pending_frame*>(pending));
+    return guarded([&] {
+        auto frame = p->fut.get();
+        if (out && p->readback) {
+            if (frame.size() > capacity)
+                throw invalid_argument("output buffer too small");
+            std::memcpy(out, frame.data(), frame.size());
+        }
+        if (kernel_ms)
+            *kernel_ms = p->mixer->last_kernel_ms();
     });
 }
 

@@ -31,13 +31,16 @@ def make_plane(w, h, channels, kind, seed, bits=8):
     if kind == "noise":
         a = rnd
     elif kind in ("smooth", "video"):
-        y, x = np.mgrid[0:h, 0:w].astype(np.float64)
-        chans = []
+        # separable gradients (outer products of 1-D vectors: cheap at 2160p) + mild per-sample noise
+        x = np.arange(w, dtype=np.float64)
+        y = np.arange(h, dtype=np.float64)
+        a = np.empty((h, w, channels), dtype=np.float64)
         for k in range(channels):
-            f = 0.5 + 0.38 * np.sin(x / (9.0 + 2 * k + seed % 5) + k + seed) * np.cos(y / (7.0 + k + seed % 3) - seed)
-            f = f + 0.1 * (x / max(1, w - 1) - 0.5) + (rnd[..., k] - 0.5) * 0.04
-            chans.append(f)
-        a = np.clip(np.stack(chans, -1), 0.0, 1.0)
+            fx = np.sin(x / (9.0 + 2 * k + seed % 5) + k + seed)
+            fy = np.cos(y / (7.0 + k + seed % 3) - seed)
+            a[..., k] = 0.5 + 0.38 * np.outer(fy, fx) + 0.1 * (x / max(1, w - 1) - 0.5)[None, :]
+        a += (rnd - 0.5) * 0.04
+        np.clip(a, 0.0, 1.0, out=a)
         if kind == "video":
             a = (16.0 + a * 219.0) / 255.0
     elif kind == "premul":
