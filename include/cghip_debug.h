@@ -19,6 +19,10 @@ int cghip_debug_kop_size(void);
 /* A plane descriptor with no device memory behind it, for planner tests. Release with cghip_plane_release. */
 int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_plane** out);
 
+/* Forces the general one-pixel-per-lane kernel even for frames the 4-pixels-per-lane kernel could run, so
+ * tests can compare the two. */
+void cghip_debug_force_general_kernel(int on);
+
 #ifdef __cplusplus
 }
 #endif

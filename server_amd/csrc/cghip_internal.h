@@ -91,6 +91,7 @@ namespace cghip {
 struct frame_plan {
     std::vector<KOp> ops;
     bool             full = false; /* needs the RGBA1/RGBA2 register surfaces */
+    bool             fast = false; /* every draw qualifies for cghip_composite_fast */
     std::vector<cghip_plane*> planes; /* every plane referenced by an emitted op */
 };
 
@@ -101,6 +102,6 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
 } // namespace cghip
 
 extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
-                                             int field_mode, int full, hipStream_t stream);
+                                             int field_mode, int full, int fast, hipStream_t stream);
 
 #endif

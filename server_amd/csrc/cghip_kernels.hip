@@ -517,6 +517,7 @@ DEV f4 source_color_unit(const KOp& op, int px, int py)
 
 /* shader.frag:523-541 after get_rgba_color: adjustments, keys, opacity, invert, blend; returns the
  * UNQUANTISED result in internal order. back = current content of the destination surface. */
+template <bool BLEND = true>
 DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
 {
     if (op.flags & KF_CHROMA)
@@ -536,7 +537,7 @@ DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
     if (op.flags & KF_INVERT)
         color = f4{1.0f - color.x, 1.0f - color.y, 1.0f - color.z, 1.0f - color.w};
     f4 fore = color;
-    if (op.blend_mode != 0) { /* shader.frag:427-428 */
+    if (BLEND && op.blend_mode != 0) { /* shader.frag:427-428 */
         const float ib = 1.0f / (back.w + 0.0000001f), ifo = 1.0f / (fore.w + 0.0000001f);
         const f3    bc = get_blend_color(op.blend_mode, f3{back.x * ib, back.y * ib, back.z * ib},
                                       f3{fore.x * ifo, fore.y * ifo, fore.z * ifo});
@@ -666,12 +667,255 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
     }
 }
 
+/* ------------------------------------------------------------------ the fast compositor */
+
+/* Out-of-line per-pixel source fetch for the few lanes of the fast kernel that straddle an op's edge. */
+__device__ __noinline__ f4 source_unit_slow(const KOp& op, int px, int py) { return source_color_unit(op, px, py); }
+
+DEV float lerpf(float a, float b, float w) { return a + w * (b - a); }
+DEV int   lerp8i(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); }
+
+/* Four horizontally adjacent samples of a 1-channel plane for output texels sx..sx+3 (sx % 4 == 0), at
+ * unit scale (half == 0: texel = sx+i) or from a half-width plane (half == 1: texel centres fall at 1/4 and
+ * 3/4 between neighbours, weights 0.75 / 0.25 exactly). Row r of the plane. Values are returned as the
+ * floats texture() would give. 16-bit: fp32 lerp; 8-bit: rounded integer lerp with 8-bit weights. */
+template <int SRC_BITS>
+DEV void row4(const KPlane& p, int r, int sx, int half, float o[4])
+{
+    if (SRC_BITS == 16) {
+        const uint16_t* row = (const uint16_t*)p.ptr + (size_t)r * (size_t)p.w;
+        const float     sc  = 1.0f / 65535.0f;
+        if (!half) {
+            const uint2 v = *(const uint2*)(row + sx);
+            o[0] = (float)(v.x & 0xffff) * sc, o[1] = (float)(v.x >> 16) * sc;
+            o[2] = (float)(v.y & 0xffff) * sc, o[3] = (float)(v.y >> 16) * sc;
+        } else {
+            const int      k  = sx >> 1;
+            const uint32_t m  = *(const uint32_t*)(row + k);
+            const float    t0 = (float)(m & 0xffff) * sc, t1 = (float)(m >> 16) * sc;
+            const float    tl = (float)row[imax(k - 1, 0)] * sc, tr = (float)row[imin(k + 2, p.w - 1)] * sc;
+            o[0] = lerpf(tl, t0, 0.75f), o[1] = lerpf(t0, t1, 0.25f);
+            o[2] = lerpf(t0, t1, 0.75f), o[3] = lerpf(t1, tr, 0.25f);
+        }
+    } else {
+        const uint8_t* row = (const uint8_t*)p.ptr + (size_t)r * (size_t)p.w;
+        int            q[4];
+        if (!half) {
+            const uint32_t v = *(const uint32_t*)(row + sx);
+            q[0] = v & 0xff, q[1] = (v >> 8) & 0xff, q[2] = (v >> 16) & 0xff, q[3] = v >> 24;
+        } else {
+            const int      k  = sx >> 1;
+            const uint32_t m  = *(const uint16_t*)(row + k);
+            const int      t0 = m & 0xff, t1 = m >> 8;
+            const int      tl = row[imax(k - 1, 0)], tr = row[imin(k + 2, p.w - 1)];
+            q[0] = lerp8i(tl, t0, 192), q[1] = lerp8i(t0, t1, 64);
+            q[2] = lerp8i(t0, t1, 192), q[3] = lerp8i(t1, tr, 64);
+        }
+        /* the integer results are returned un-normalised; plane4 scales after the optional row lerp */
+        o[0] = (float)q[0], o[1] = (float)q[1], o[2] = (float)q[2], o[3] = (float)q[3];
+    }
+}
+
+/* plane4: row4 plus the vertical half-resolution lerp (4:2:0), x first then y like the sampler. */
+template <int SRC_BITS>
+DEV void plane4(const KPlane& p, int sx, int sy, int halfx, int halfy, float o[4])
+{
+    if (!halfy) {
+        row4<SRC_BITS>(p, sy, sx, halfx, o);
+    } else {
+        /* v = (sy + .5)/2 - .5: even rows sit 3/4 of the way from row sy/2-1 to sy/2, odd rows 1/4 from (sy-1)/2 */
+        const int   r0 = (sy - 1) >> 1;
+        const bool  odd = sy & 1;
+        float       a[4], b[4];
+        row4<SRC_BITS>(p, iclamp(r0, 0, p.h - 1), sx, halfx, a);
+        row4<SRC_BITS>(p, iclamp(r0 + 1, 0, p.h - 1), sx, halfx, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (SRC_BITS == 16)
+                o[i] = lerpf(a[i], b[i], odd ? 0.25f : 0.75f);
+            else
+                o[i] = (float)lerp8i((int)a[i], (int)b[i], odd ? 64 : 192);
+        }
+    }
+    if (SRC_BITS == 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] *= (1.0f / 255.0f);
+    }
+}
+
+/* source colours of four adjacent pixels, FC_PLANAR / FC_PACKED ops (vector loads) */
+template <int SRC_BITS>
+DEV void fetch4(const KOp& op, int sx, int sy, f4 col[4])
+{
+    if (op.fast_class == FC_PLANAR) {
+        float Y[4], Cb[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        plane4<SRC_BITS>(op.planes[0], sx, sy, 0, 0, Y);
+        plane4<SRC_BITS>(op.planes[1], sx, sy, op.csx, op.csy, Cb);
+        plane4<SRC_BITS>(op.planes[2], sx, sy, op.csx, op.csy, Cr);
+        if (op.pixel_format == 6)
+            plane4<SRC_BITS>(op.planes[3], sx, sy, 0, 0, Al);
+        const bool hd = op.flags & KF_IS_HD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            col[i] = ycbcra_to_rgba(Y[i], Cb[i], Cr[i], Al[i], hd);
+    } else { /* FC_PACKED: one 4-channel plane */
+        const KPlane& p = op.planes[0];
+        if (SRC_BITS == 8) {
+            const uint4    v    = *(const uint4*)((const uint32_t*)p.ptr + (size_t)sy * (size_t)p.w + sx);
+            const uint32_t m[4] = {v.x, v.y, v.z, v.w};
+            const float    sc   = 1.0f / 255.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                col[i] = swizzle_format(op.pixel_format,
+                                        f4{(float)((m[i] >> 16) & 0xff) * sc, (float)((m[i] >> 8) & 0xff) * sc,
+                                           (float)(m[i] & 0xff) * sc, (float)(m[i] >> 24) * sc});
+        } else {
+            const uint4* src = (const uint4*)((const uint2*)p.ptr + (size_t)sy * (size_t)p.w + sx);
+            const uint4  a = src[0], b = src[1];
+            const uint32_t m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const float    sc   = 1.0f / 65535.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                col[i] = swizzle_format(op.pixel_format,
+                                        f4{(float)(m[2 * i + 1] & 0xffff) * sc, (float)(m[2 * i] >> 16) * sc,
+                                           (float)(m[2 * i] & 0xffff) * sc, (float)(m[2 * i + 1] >> 16) * sc});
+        }
+    }
+}
+
+/* Fast compositor: frames whose every draw is a unit-scale, normal-blend layer (full-screen video stacks
+ * with key layers, chroma key, levels, CSB: BASELINE configs 1, 3 and most of a live rundown). Four pixels
+ * per lane: a wave owns 256 consecutive pixels of a row, sources arrive through aligned 4..32-byte loads,
+ * the frame leaves through 16/32-byte stores. Numerics are those of cghip_composite. */
+template <int BITS>
+__global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
+                                                            int W, int H, int field_mode)
+{
+    constexpr int P    = 4;
+    const int     lane = threadIdx.x & 63;
+    const int     wave = threadIdx.x >> 6;
+    const int     y    = blockIdx.y * 4 + wave;
+    if (y >= H)
+        return;
+    const int wave_x0 = blockIdx.x * 64 * P;
+    const int wave_x1 = wave_x0 + 64 * P;
+    const int px0     = wave_x0 + lane * P;
+
+    f4    S[P];
+    float K0[P], K1[P];
+    static_for<0, P>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        S[i]  = f4{0, 0, 0, 0};
+        K0[i] = K1[i] = 0.0f;
+    });
+    const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
+
+    for (int n = 0; n < nops && row_live; ++n) {
+        const KOp& op = ops[n];
+        if (op.kind == KOP_CLEAR) {
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                K0[i] = op.dst == KS_KEY0 ? 0.0f : K0[i];
+                K1[i] = op.dst == KS_KEY1 ? 0.0f : K1[i];
+            });
+            continue;
+        }
+        if (y < op.y0 || y >= op.y1 || wave_x1 <= op.x0 || wave_x0 >= op.x1)
+            continue;
+        const int cx0 = imax(px0, op.x0), cx1 = imin(px0 + P, op.x1);
+        if (cx0 >= cx1)
+            continue;
+        const int  sx = px0 + op.unit_dx, sy = y + op.unit_dy;
+        const bool vec = cx0 == px0 && cx1 == px0 + P && (sx & 3) == 0 && sx >= 0 && sx + P <= op.planes[0].w &&
+                         sy >= 0 && sy < op.planes[0].h;
+        f4 col[P];
+        if (vec) {
+            if (op.planes[0].bits == 16)
+                fetch4<16>(op, sx, sy, col);
+            else
+                fetch4<8>(op, sx, sy, col);
+        } else {
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                col[i]          = f4{0, 0, 0, 0};
+                if (px0 + i >= cx0 && px0 + i < cx1)
+                    col[i] = source_unit_slow(op, sx + i, sy);
+            });
+        }
+        const bool to_key = op.dst >= KS_KEY0, key1 = op.dst == KS_KEY1;
+        static_for<0, P>([&](auto I) {
+            constexpr int i  = decltype(I)::value;
+            const float   a0 = K0[i], a1 = K1[i];
+            const float   lkey = op.local_key == KS_KEY1 ? a1 : a0;
+            const float   ykey = op.layer_key == KS_KEY1 ? a1 : a0;
+            const bool    in   = px0 + i >= cx0 && px0 + i < cx1;
+            const f4      cur  = S[i];
+            const f4      back = to_key ? f4{0.0f, 0.0f, key1 ? a1 : a0, 1.0f} : cur;
+            const f4      res  = shade<false>(op, col[i], lkey, ykey, back);
+            const f4      q    = f4{quantize<BITS>(res.x), quantize<BITS>(res.y), quantize<BITS>(res.z), quantize<BITS>(res.w)};
+            const bool    wr_s = in && !to_key, wr_0 = in && to_key && !key1, wr_1 = in && to_key && key1;
+            S[i]  = f4{wr_s ? q.x : cur.x, wr_s ? q.y : cur.y, wr_s ? q.z : cur.z, wr_s ? q.w : cur.w};
+            K0[i] = wr_0 ? q.z : a0;
+            K1[i] = wr_1 ? q.z : a1;
+        });
+    }
+
+    if (px0 >= W)
+        return;
+    if (BITS == 8) {
+        uint32_t v[P];
+        static_for<0, P>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            v[i] = to_code<8>(S[i].x) | (to_code<8>(S[i].y) << 8) | (to_code<8>(S[i].z) << 16) | (to_code<8>(S[i].w) << 24);
+        });
+        uint32_t* o = (uint32_t*)out + (size_t)y * W + px0;
+        if (px0 + P <= W && (W & 3) == 0) {
+            *(uint4*)o = uint4{v[0], v[1], v[2], v[3]};
+        } else {
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if (px0 + i < W)
+                    o[i] = v[i];
+            });
+        }
+    } else {
+        uint2 v[P];
+        static_for<0, P>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            v[i] = uint2{to_code<16>(S[i].x) | (to_code<16>(S[i].y) << 16), to_code<16>(S[i].z) | (to_code<16>(S[i].w) << 16)};
+        });
+        uint2* o = (uint2*)out + (size_t)y * W + px0;
+        if (px0 + P <= W && (W & 1) == 0) {
+            ((uint4*)o)[0] = uint4{v[0].x, v[0].y, v[1].x, v[1].y};
+            ((uint4*)o)[1] = uint4{v[2].x, v[2].y, v[3].x, v[3].y};
+        } else {
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if (px0 + i < W)
+                    o[i] = v[i];
+            });
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
 
+static int g_force_general = 0;
+extern "C" void cghip_debug_force_general_kernel(int on) { g_force_general = on; }
+
 extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
-                                             int field_mode, int full, hipStream_t stream)
+                                             int field_mode, int full, int fast, hipStream_t stream)
 {
     dim3 block(256);
+    if (fast && !full && !g_force_general) {
+        dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4));
+        if (bits == 8)
+            hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+        else
+            hipLaunchKernelGGL((cghip_composite_fast<16>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4));
     if (bits == 8) {
         if (full)

@@ -32,6 +32,12 @@ enum KOpFlags : uint32_t {
     KF_ADDITIVE    = 1u << 9  /* keyer::additive */
 };
 
+enum KFastClass : int32_t {
+    FC_NONE   = 0,
+    FC_PACKED = 1, /* one 4-channel plane (bgra / rgba / argb / abgr), unit scale */
+    FC_PLANAR = 2  /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
+};
+
 /* register-resident surfaces the kernel has names for */
 enum KSurf : int32_t {
     KS_NONE = -1,
@@ -79,7 +85,9 @@ struct KOp {
     float   brt, sat, con;
     float   ch_target_hue, ch_hue_width, ch_min_saturation, ch_min_brightness, ch_softness, ch_spill,
         ch_spill_saturation;
-    float   pad_[3];
+    /* fast-path classification (host, cghip_plan.cpp): 0 = general kernel only; FC_* otherwise */
+    int32_t fast_class;
+    int32_t csx, csy; /* FC_PLANAR: chroma planes are 1/2 width (csx) and/or 1/2 height (csy) of plane 0 */
     KPlane  planes[4];
     KTri    tri[2];
 };

@@ -184,6 +184,45 @@ int floor_div256(int64_t v) { return (int)((v >= 0) ? v / 256 : -((-v + 255) / 2
 
 } // namespace
 
+/* Which draws the 4-pixels-per-lane kernel (cghip_composite_fast) can run: unit-scale sources whose texels
+ * can be fetched with aligned vector loads, normal blend into the frame or a key surface. */
+static void classify_fast(KOp& op)
+{
+    op.fast_class = FC_NONE;
+    op.csx = op.csy = 0;
+    if (op.kind != KOP_DRAW_PLANES || !(op.flags & KF_UNIT_SCALE) || op.blend_mode != 0 || (op.flags & KF_ADDITIVE))
+        return;
+    if (op.dst != KS_RGBA0 && op.dst != KS_KEY0 && op.dst != KS_KEY1)
+        return; /* dst is bound later; re-checked in plan_frame */
+    const KPlane& p0 = op.planes[0];
+    if ((p0.w & 3) != 0)
+        return; /* rows must keep 4-texel groups aligned */
+    const int pf = op.pixel_format;
+    if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
+        op.fast_class = FC_PACKED;
+        return;
+    }
+    if ((pf == 5 && op.nplanes == 3) || (pf == 6 && op.nplanes == 4)) {
+        for (int n = 0; n < op.nplanes; ++n)
+            if (op.planes[n].channels != 1 || op.planes[n].bits != p0.bits)
+                return;
+        const KPlane &cb = op.planes[1], &cr = op.planes[2];
+        if (cb.w != cr.w || cb.h != cr.h)
+            return;
+        if (pf == 6 && (op.planes[3].w != p0.w || op.planes[3].h != p0.h))
+            return;
+        const bool fullx = cb.w == p0.w, halfx = cb.w * 2 == p0.w;
+        const bool fully = cb.h == p0.h, halfy = cb.h * 2 == p0.h;
+        if (!(fullx || halfx) || !(fully || halfy))
+            return;
+        if (halfx && (cb.w & 1) != 0)
+            return;
+        op.csx        = halfx ? 1 : 0;
+        op.csy        = halfy ? 1 : 0;
+        op.fast_class = FC_PLANAR;
+    }
+}
+
 /* One reference draw -> one KOp. Returns 1 emitted, 0 skipped (reference early-out), <0 error. */
 static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
 {
@@ -361,6 +400,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
     out->ops.clear();
     out->planes.clear();
     out->full = false;
+    out->fast = false;
     if (!fmt || fmt->width <= 0 || fmt->height <= 0 || (fmt->bits != 8 && fmt->bits != 16))
         return fail(CGHIP_ERR_INVALID, "bad cghip_format");
     if (nsurfaces < 1 || nsurfaces > CGHIP_MAX_SURFACES || !surfaces || surfaces[0].channels != 4)
@@ -450,11 +490,16 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
                         "frame needs more than 2 live RGBA temporaries or 2 live key textures at once");
         if (surfaces[d.target].channels == 1 && d.source_surface >= 0)
             return fail(CGHIP_ERR_INVALID, "surface-to-key draws do not exist in the reference renderer");
+        classify_fast(op); /* dst is known now */
         out->ops.push_back(op);
         if (d.source_surface < 0)
             for (int n = 0; n < d.nplanes; ++n)
                 out->planes.push_back(const_cast<cghip_plane*>(d.planes[n]));
     }
+    out->fast = !out->full;
+    for (const KOp& o : out->ops)
+        if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
+            out->fast = false;
     return CGHIP_OK;
 }
 
@@ -472,7 +517,7 @@ extern "C" int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* su
     if (nops)
         *nops = (int)plan.ops.size();
     if (full)
-        *full = plan.full ? 1 : 0;
+        *full = (plan.full ? 1 : 0) | (plan.fast ? 2 : 0);
     if (kops_out) {
         const int n = std::min(capacity, (int)plan.ops.size());
         std::memcpy(kops_out, plan.ops.data(), (size_t)n * sizeof(KOp));

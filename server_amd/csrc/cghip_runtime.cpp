@@ -473,7 +473,7 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     T_HIP(hipEventRecord(t->ev_start, t->stream));
     /* empty scene: the kernel with zero ops writes the all-zero frame (image_mixer.cpp:89-92) */
     T_HIP(cghip_launch_composite((const KOp*)t->d_ops, (int)plan.ops.size(), t->d_out, format->width, format->height,
-                                 format->bits, format->field_mode, plan.full ? 1 : 0, t->stream));
+                                 format->bits, format->field_mode, plan.full ? 1 : 0, plan.fast ? 1 : 0, t->stream));
     t->launches = 1;
     T_HIP(hipEventRecord(t->ev_stop, t->stream));
     if (flags & CGHIP_RENDER_READBACK) {

@@ -25,7 +25,7 @@ class KOp(C.Structure):
         ("ch_target_hue", C.c_float), ("ch_hue_width", C.c_float), ("ch_min_saturation", C.c_float),
         ("ch_min_brightness", C.c_float), ("ch_softness", C.c_float), ("ch_spill", C.c_float),
         ("ch_spill_saturation", C.c_float),
-        ("pad_", C.c_float * 3),
+        ("fast_class", C.c_int32), ("csx", C.c_int32), ("csy", C.c_int32),
         ("planes", KPlane * 4), ("tri", KTri * 2),
     ]
 
@@ -48,4 +48,4 @@ def plan(fmt, surfaces, draws):
     rc = L.cghip_debug_plan(C.byref(fmt), sa, len(surfaces), da, len(draws), out, 512, C.byref(n), C.byref(full))
     if rc != 0:
         raise A.CGHIPError(rc, L.cghip_last_error().decode())
-    return [out[i] for i in range(n.value)], bool(full.value)
+    return [out[i] for i in range(n.value)], bool(full.value & 1)

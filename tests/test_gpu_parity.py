@@ -112,6 +112,37 @@ def test_device_resident_frame_path(mixer):
     assert mixer.get(p, want_output=False) is None and mixer.last_kernel_ms > 0.0
 
 
+def test_fast_kernel_equals_general_kernel(mixer):
+    """Frames made only of unit-scale normal-blend layers run the 4-pixels-per-lane kernel; it must agree with the
+    general kernel to the last bit on 8-bit sources and within fp32-weight noise (1 LSB16) on 16-bit ones."""
+    import server_amd as A
+    L = A.lib()
+    W, H = 776, 142  # neither a multiple of 256 nor of 4 rows: exercises edge lanes
+    for bits in (8, 16):
+        sc = S.scene("fast", W, H, [
+            S.layer(S.bgra(W, H, "premul", 700, bits=bits)),
+            S.layer(S.ycbcr(W, H, "422", "smooth", 701, bits=bits), is_key=1),
+            S.layer(S.ycbcr(W, H, "422", "video", 702, bits=bits), opacity=0.8, **S.CHROMA),
+            S.layer(S.ycbcr(W, H, "420", "video", 703, bits=bits), opacity=0.7, crop_ul=[0.25, 0.125], crop_lr=[0.75, 0.875], **S.LEVELS),
+            S.layer(S.ycbcr(W, H, "444", "video", 704, bits=bits, alpha=True), opacity=0.6, clip_translation=[0.1, 0.1], clip_scale=[0.55, 0.6]),
+            S.layer(S.frame("argb", [(W, H, 4, "premul", 705)], bits), opacity=0.5, brightness=1.1, invert=1),
+        ], bits=bits)
+        fast = S.run_product(sc, mixer=mixer)
+        L.cghip_debug_force_general_kernel(1)
+        try:
+            general = S.run_product(sc, mixer=mixer)
+        finally:
+            L.cghip_debug_force_general_kernel(0)
+        st = S.diff_stats(fast, general)
+        if bits == 8:
+            assert st["max"] == 0, st
+        else:
+            assert st["gt1"] <= 1e-4 and st["gt0"] <= 2e-2, st
+        ref = S.run_oracle(sc, "cpu")
+        so = S.diff_stats(fast, ref)
+        assert (so["max"] <= 1 and so["gt0"] <= 2e-3) if bits == 8 else (so["gt2"] <= 1e-4), so
+
+
 FULL = [("config1", lambda: S.config1()), ("config2", lambda: S.config2()), ("config4", lambda: S.config4()),
         ("config3_8bit", lambda: S.config3(bits=8)), ("config3_16bit", lambda: S.config3(bits=16))]
 
