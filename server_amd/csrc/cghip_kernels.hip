@@ -57,10 +57,11 @@ struct Q {
 template <int BITS>
 DEV float quantize(float x)
 {
-    x       = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); /* NaN -> 0 like the clamp before a UNORM store */
-    float r = __fadd_rn(__fmul_rn(x, Q<BITS>::scale), Q<BITS>::magic);
-    float t = __fsub_rn(r, Q<BITS>::magic); /* = k / 2^n exactly */
-    return __fmul_rn(t, Q<BITS>::dequant);  /* = fl(k * fl(1/(2^n-1))) */
+#pragma clang fp contract(off)
+    x             = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); /* NaN -> 0 like the clamp before a UNORM store */
+    const float r = x * Q<BITS>::scale + Q<BITS>::magic; /* two roundings, never an fma (pragma above) */
+    const float t = r - Q<BITS>::magic;                  /* = k / 2^n exactly */
+    return t * Q<BITS>::dequant;                         /* = fl(k * fl(1/(2^n-1))) */
 }
 template <int BITS>
 DEV uint32_t to_code(float q)
@@ -225,6 +226,16 @@ DEV float div_const(float x, float c, float rc)
     return __builtin_fmaf(r, rc, q);
 }
 
+/* a / b with one Newton step on v_rcp_f32: correctly rounded for the finite, non-zero denominators this shader
+ * produces (alpha + 1e-7, 6d + 1e-10, ...), in ~5 issue slots instead of the ~14 of the IEEE divide sequence. */
+DEV float fdiv(float a, float b)
+{
+    const float rb = __builtin_amdgcn_rcpf(b);
+    const float q  = a * rb;
+    const float r  = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(r, rb, q);
+}
+
 /* shader.frag:441-467; internal order x=blue y=green z=red w=alpha */
 DEV f4 ycbcra_to_rgba(float Y, float Cb, float Cr, float A, bool hd)
 {
@@ -244,16 +255,17 @@ DEV f4 ycbcra_to_rgba(float Y, float Cb, float Cr, float A, bool hd)
     return c;
 }
 
-/* shader.frag:304-321 */
+/* shader.frag:304-321. step() yields exactly 0 or 1, and mix(a, b, 0|1) = a*(1-t) + b*t is then exactly a or b,
+ * so the seven mixes are selects. */
 DEV f3 rgb2hsv(f3 c)
 {
-    const float st = c.y < c.z ? 0.0f : 1.0f; /* step(c.b, c.g) */
-    const f4    p  = {mixf(c.z, c.y, st), mixf(c.y, c.z, st), mixf(-1.0f, 0.0f, st), mixf(2.0f / 3.0f, -1.0f / 3.0f, st)};
-    const float s2 = c.x < p.x ? 0.0f : 1.0f; /* step(p.x, c.r) */
-    const f4    q  = {mixf(p.x, c.x, s2), p.y, mixf(p.w, p.z, s2), mixf(c.x, p.x, s2)};
+    const bool  gb = !(c.y < c.z); /* step(c.b, c.g) == 1 */
+    const f4    p  = {gb ? c.y : c.z, gb ? c.z : c.y, gb ? 0.0f : -1.0f, gb ? -1.0f / 3.0f : 2.0f / 3.0f};
+    const bool  rp = !(c.x < p.x); /* step(p.x, c.r) == 1 */
+    const f4    q  = {rp ? c.x : p.x, p.y, rp ? p.z : p.w, rp ? p.x : c.x};
     const float d  = q.x - __builtin_fminf(q.w, q.y);
     const float e  = 1.0e-10f;
-    return f3{__builtin_fabsf(q.z + (q.w - q.y) / (6.0f * d + e)), d / (q.x + e), q.x};
+    return f3{__builtin_fabsf(q.z + fdiv(q.w - q.y, 6.0f * d + e)), fdiv(d, q.x + e), q.x};
 }
 DEV f3 hsv2rgb(f3 c)
 {
@@ -265,7 +277,7 @@ DEV f3 hsv2rgb(f3 c)
 }
 
 /* shader.frag:323-383,436-439; colour in internal order */
-__device__ __noinline__ f4 chroma_key(f4 c, const KOp& op)
+DEV f4 chroma_key(f4 c, const KOp& op)
 {
     const f3    hsv      = rgb2hsv(f3{c.z, c.y, c.x}); /* c.bgra -> real r,g,b */
     const float hueDiff  = (0.5f - __builtin_fabsf(__builtin_fabsf(hsv.x - op.ch_target_hue) - 0.5f)) * 2.0f;
@@ -278,13 +290,13 @@ __device__ __noinline__ f4 chroma_key(f4 c, const KOp& op)
     f3          sp       = hsv;
     float       diff     = hsv.x - op.ch_target_hue;
     diff                 = diff < -0.5f ? diff + 1.0f : (diff > 0.5f ? diff - 1.0f : diff);
-    const float dist     = __builtin_fabsf(diff) / op.ch_spill;
+    const float dist     = __builtin_fabsf(diff) * op.ch_inv_spill;
     if (dist < 1.0f) {
         sp.x = diff < 0.0f ? op.ch_target_hue - op.ch_spill : op.ch_target_hue + op.ch_spill;
         sp.y *= __builtin_fminf(1.0f, dist + op.ch_spill_saturation);
     }
     const f3    rgb   = hsv2rgb(sp);
-    const float t     = clamp01((dd - 1.0f) / (op.ch_softness - 1.0f)); /* smoothstep(1, softness, d) */
+    const float t     = clamp01((dd - 1.0f) * op.ch_inv_soft); /* smoothstep(1, softness, d) */
     const float alpha = 1.0f - t * t * (3.0f - 2.0f * t);
     if (op.flags & KF_CHROMA_MASK)
         return f4{alpha, alpha, alpha, 1.0f};
@@ -296,6 +308,8 @@ DEV float levels1(float c, const KOp& op)
 {
     float r = __builtin_fminf(__builtin_fmaxf(c - op.lv_min_input, 0.0f) * op.lv_inv_range, 1.0f);
     r       = __builtin_amdgcn_exp2f(op.lv_inv_gamma * __builtin_amdgcn_logf(r)); /* pow(r, 1/gamma), r in [0,1] */
+    if (op.lv_min_output == 0.0f && op.lv_max_output == 1.0f)
+        return r; /* mix(0, 1, r) = 0*(1-r) + 1*r is exactly r */
     return mixf(op.lv_min_output, op.lv_max_output, r);
 }
 
@@ -306,8 +320,7 @@ DEV void csb(f4& color, const KOp& op)
     const f3   L  = hd ? f3{0.0722f, 0.7152f, 0.2126f} : f3{0.114f, 0.587f, 0.299f};
     f3         c  = {color.x, color.y, color.z};
     if (color.w > 0.0f) {
-        const float ia = 1.0f / color.w;
-        c.x *= ia, c.y *= ia, c.z *= ia;
+        c.x = fdiv(c.x, color.w), c.y = fdiv(c.y, color.w), c.z = fdiv(c.z, color.w);
     }
     const f3    b = {c.x * op.brt, c.y * op.brt, c.z * op.brt};
     const float i = b.x * L.x + b.y * L.y + b.z * L.z;
@@ -517,8 +530,8 @@ DEV f4 source_color_unit(const KOp& op, int px, int py)
 
 /* shader.frag:523-541 after get_rgba_color: adjustments, keys, opacity, invert, blend; returns the
  * UNQUANTISED result in internal order. back = current content of the destination surface. */
-template <bool BLEND = true>
-DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
+/* shader.frag:526-531: chroma key, levels, CSB on the source colour */
+DEV f4 shade_adjust(const KOp& op, f4 color)
 {
     if (op.flags & KF_CHROMA)
         color = chroma_key(color, op);
@@ -529,6 +542,16 @@ DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
     }
     if (op.flags & KF_CSB)
         csb(color, op);
+    return color;
+}
+
+/* shader.frag:532-541: keys, opacity, invert, blend. No FMA contraction in here: llvmpipe evaluates these
+ * unfused, and with "nice" opacities (0.5, 0.25 ...) the UNORM store that follows hits exact .5 ties that only
+ * the same sequence of roundings resolves the same way. Returns the UNQUANTISED result, internal order. */
+template <bool BLEND>
+DEV f4 shade_blend(const KOp& op, f4 color, float lkey, float ykey, f4 back)
+{
+#pragma clang fp contract(off)
     if (op.local_key != KS_NONE)
         color.x *= lkey, color.y *= lkey, color.z *= lkey, color.w *= lkey;
     if (op.layer_key != KS_NONE)
@@ -538,15 +561,21 @@ DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
         color = f4{1.0f - color.x, 1.0f - color.y, 1.0f - color.z, 1.0f - color.w};
     f4 fore = color;
     if (BLEND && op.blend_mode != 0) { /* shader.frag:427-428 */
-        const float ib = 1.0f / (back.w + 0.0000001f), ifo = 1.0f / (fore.w + 0.0000001f);
-        const f3    bc = get_blend_color(op.blend_mode, f3{back.x * ib, back.y * ib, back.z * ib},
-                                      f3{fore.x * ifo, fore.y * ifo, fore.z * ifo});
+        const float ba = back.w + 0.0000001f, fa = fore.w + 0.0000001f;
+        const f3    bc = get_blend_color(op.blend_mode, f3{fdiv(back.x, ba), fdiv(back.y, ba), fdiv(back.z, ba)},
+                                      f3{fdiv(fore.x, fa), fdiv(fore.y, fa), fdiv(fore.z, fa)});
         fore.x = bc.x * fore.w, fore.y = bc.y * fore.w, fore.z = bc.z * fore.w;
     }
     if (op.flags & KF_ADDITIVE) /* shader.frag:429-433 */
         return f4{fore.x + back.x, fore.y + back.y, fore.z + back.z, fore.w + back.w};
     const float ia = 1.0f - fore.w;
     return f4{fore.x + ia * back.x, fore.y + ia * back.y, fore.z + ia * back.z, fore.w + ia * back.w};
+}
+
+template <bool BLEND = true>
+DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
+{
+    return shade_blend<BLEND>(op, shade_adjust(op, color), lkey, ykey, back);
 }
 
 /* ------------------------------------------------------------------ the compositor */
@@ -669,9 +698,6 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 
 /* ------------------------------------------------------------------ the fast compositor */
 
-/* Out-of-line per-pixel source fetch for the few lanes of the fast kernel that straddle an op's edge. */
-__device__ __noinline__ f4 source_unit_slow(const KOp& op, int px, int py) { return source_color_unit(op, px, py); }
-
 DEV float lerpf(float a, float b, float w) { return a + w * (b - a); }
 DEV int   lerp8i(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); }
 
@@ -784,10 +810,12 @@ DEV void fetch4(const KOp& op, int sx, int sy, f4 col[4])
     }
 }
 
-/* Fast compositor: frames whose every draw is a unit-scale, normal-blend layer (full-screen video stacks
- * with key layers, chroma key, levels, CSB: BASELINE configs 1, 3 and most of a live rundown). Four pixels
- * per lane: a wave owns 256 consecutive pixels of a row, sources arrive through aligned 4..32-byte loads,
- * the frame leaves through 16/32-byte stores. Numerics are those of cghip_composite. */
+/* Fast compositor: frames whose every draw is a unit-scale, normal-blend layer whose pixel box and source offset
+ * are multiples of 4 pixels (full-screen video stacks with key layers, chroma key, levels, CSB: BASELINE configs
+ * 1, 3 and most of a live rundown). Four pixels per lane: a wave owns 256 consecutive pixels of a row, sources
+ * arrive through aligned 4..32-byte loads, the frame leaves through 16/32-byte stores; a lane is either wholly
+ * inside an op's box or wholly outside it, so there is no per-pixel predication. Numerics are those of
+ * cghip_composite. */
 template <int BITS>
 __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
                                                             int W, int H, int field_mode)
@@ -823,42 +851,34 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         }
         if (y < op.y0 || y >= op.y1 || wave_x1 <= op.x0 || wave_x0 >= op.x1)
             continue;
-        const int cx0 = imax(px0, op.x0), cx1 = imin(px0 + P, op.x1);
-        if (cx0 >= cx1)
-            continue;
-        const int  sx = px0 + op.unit_dx, sy = y + op.unit_dy;
-        const bool vec = cx0 == px0 && cx1 == px0 + P && (sx & 3) == 0 && sx >= 0 && sx + P <= op.planes[0].w &&
-                         sy >= 0 && sy < op.planes[0].h;
-        f4 col[P];
-        if (vec) {
-            if (op.planes[0].bits == 16)
-                fetch4<16>(op, sx, sy, col);
-            else
-                fetch4<8>(op, sx, sy, col);
+        if (px0 < op.x0 || px0 >= op.x1)
+            continue; /* op.x0, op.x1 are multiples of 4: the lane is all in or all out */
+        const int sx = px0 + op.unit_dx, sy = y + op.unit_dy;
+        f4        col[P];
+        if (op.planes[0].bits == 16)
+            fetch4<16>(op, sx, sy, col);
+        else
+            fetch4<8>(op, sx, sy, col);
+        if (op.dst >= KS_KEY0) { /* key surface: only the red slot is stored (image_mixer.cpp:174-183) */
+            const bool key1 = op.dst == KS_KEY1;
+            static_for<0, P>([&](auto I) {
+                constexpr int i  = decltype(I)::value;
+                const float   a0 = K0[i], a1 = K1[i];
+                const f4      r  = shade<false>(op, col[i], a0, a0, f4{0.0f, 0.0f, key1 ? a1 : a0, 1.0f});
+                const float   q  = quantize<BITS>(r.z);
+                K0[i]            = key1 ? a0 : q;
+                K1[i]            = key1 ? q : a1;
+            });
         } else {
             static_for<0, P>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                col[i]          = f4{0, 0, 0, 0};
-                if (px0 + i >= cx0 && px0 + i < cx1)
-                    col[i] = source_unit_slow(op, sx + i, sy);
+                constexpr int i    = decltype(I)::value;
+                const float   a0   = K0[i], a1 = K1[i];
+                const float   lkey = op.local_key == KS_KEY1 ? a1 : a0;
+                const float   ykey = op.layer_key == KS_KEY1 ? a1 : a0;
+                const f4      r    = shade<false>(op, col[i], lkey, ykey, S[i]);
+                S[i] = f4{quantize<BITS>(r.x), quantize<BITS>(r.y), quantize<BITS>(r.z), quantize<BITS>(r.w)};
             });
         }
-        const bool to_key = op.dst >= KS_KEY0, key1 = op.dst == KS_KEY1;
-        static_for<0, P>([&](auto I) {
-            constexpr int i  = decltype(I)::value;
-            const float   a0 = K0[i], a1 = K1[i];
-            const float   lkey = op.local_key == KS_KEY1 ? a1 : a0;
-            const float   ykey = op.layer_key == KS_KEY1 ? a1 : a0;
-            const bool    in   = px0 + i >= cx0 && px0 + i < cx1;
-            const f4      cur  = S[i];
-            const f4      back = to_key ? f4{0.0f, 0.0f, key1 ? a1 : a0, 1.0f} : cur;
-            const f4      res  = shade<false>(op, col[i], lkey, ykey, back);
-            const f4      q    = f4{quantize<BITS>(res.x), quantize<BITS>(res.y), quantize<BITS>(res.z), quantize<BITS>(res.w)};
-            const bool    wr_s = in && !to_key, wr_0 = in && to_key && !key1, wr_1 = in && to_key && key1;
-            S[i]  = f4{wr_s ? q.x : cur.x, wr_s ? q.y : cur.y, wr_s ? q.z : cur.z, wr_s ? q.w : cur.w};
-            K0[i] = wr_0 ? q.z : a0;
-            K1[i] = wr_1 ? q.z : a1;
-        });
     }
 
     if (px0 >= W)

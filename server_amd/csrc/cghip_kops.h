@@ -87,6 +87,8 @@ struct KOp {
         ch_spill_saturation;
     /* fast-path classification (host, cghip_plan.cpp): 0 = general kernel only; FC_* otherwise */
     int32_t fast_class;
+    float   ch_inv_spill, ch_inv_soft; /* 1/ch_spill, 1/(ch_softness - 1) */
+    int32_t pad_;
     int32_t csx, csy; /* FC_PLANAR: chroma planes are 1/2 width (csx) and/or 1/2 height (csy) of plane 0 */
     KPlane  planes[4];
     KTri    tri[2];

@@ -197,6 +197,12 @@ static void classify_fast(KOp& op)
     const KPlane& p0 = op.planes[0];
     if ((p0.w & 3) != 0)
         return; /* rows must keep 4-texel groups aligned */
+    /* every lane of the fast kernel owns 4 consecutive pixels and fetches them with one aligned vector load: the
+       op's pixel box and its source offset must keep those groups whole and inside the plane */
+    if ((op.x0 & 3) != 0 || (op.x1 & 3) != 0 || (op.unit_dx & 3) != 0)
+        return;
+    if (op.x0 + op.unit_dx < 0 || op.x1 + op.unit_dx > p0.w || op.y0 + op.unit_dy < 0 || op.y1 + op.unit_dy > p0.h)
+        return;
     const int pf = op.pixel_format;
     if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
         op.fast_class = FC_PACKED;
@@ -276,6 +282,8 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
         op.ch_softness         = (float)(1.0 + t.chroma_softness);
         op.ch_spill            = (float)(t.chroma_spill_suppress / 360.0);
         op.ch_spill_saturation = (float)t.chroma_spill_suppress_saturation;
+        op.ch_inv_spill        = 1.0f / op.ch_spill; /* +inf for 0: |diff| * inf keeps the shader's x/0 behaviour */
+        op.ch_inv_soft         = 1.0f / (op.ch_softness - 1.0f);
     }
     if (t.levels_min_input > epsilon || t.levels_max_input < 1.0 - epsilon || t.levels_min_output > epsilon ||
         t.levels_max_output < 1.0 - epsilon || std::fabs(t.levels_gamma - 1.0) > epsilon) { /* :282-293 */

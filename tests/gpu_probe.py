@@ -1,0 +1,32 @@
+"""Perf probe: kernel time of single-type 16-layer stacks at 2160p (run through gpurun, optionally under rocprofv3)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import scenes as S
+import server_amd as A
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import Channel, run_steps
+
+W, H = 3840, 2160
+NL = int(os.environ.get("PROBE_LAYERS", "8"))
+def stack(kind, bits):
+    t = {"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
+         "levels": dict(opacity=0.7, **S.LEVELS), "bgra": dict(opacity=0.8)}[kind]
+    ops = []
+    for i in range(NL):
+        spec = S.bgra(W, H, "premul", 500 + i, bits=bits) if kind == "bgra" else S.ycbcr(W, H, "422", "video", 500 + i, bits=bits)
+        ops.append(S.layer(spec, **t))
+    return S.scene("%s_%d" % (kind, bits), W, H, ops, bits=bits)
+
+which = os.environ.get("PROBE", "plain,key,chroma,levels,bgra").split(",")
+for bits in (16, 8):
+    for kind in which:
+        sc = stack(kind, bits)
+        ch = Channel(A, S, sc, 0, 1)
+        run_steps(ch, 2)
+        ms = run_steps(ch, 5)
+        b = S.algorithmic_bytes(sc)
+        print("%-10s %2d-bit  %d layers  kernel %.3f ms  %.0f GB/s  (%.1f ns per Mlayer-px)" % (
+            kind, bits, NL, np.mean(ms), b / np.mean(ms) / 1e6, np.mean(ms) * 1e6 / (NL * W * H / 1e6)), flush=True)
+        ch.close()
