@@ -68,6 +68,17 @@ def dist_setup(n_gpus):
     return rank, world, local_rank, barrier, allreduce_max
 
 
+def shard_channels(n_channels, world):
+    """Channel c is placed on rank / GPU c % world (accelerator::create_image_mixer's round-robin placement):
+    channels are independent, so this is the whole of the multi-GPU decomposition."""
+    return [[c for c in range(n_channels) if c % world == r] for r in range(world)]
+
+
+def whole_job_value(world, steps, seconds):
+    """Whole-job frames/s: every rank composites `steps` frames in the (max-over-ranks) timed region."""
+    return world * steps / seconds
+
+
 def device_sync():
     try:
         import torch
@@ -216,7 +227,7 @@ def main():
                 traffic = None
         line = {
             "metric": "composited frames/s per GPU (2160p, 16 layers) + % of HBM roofline",
-            "value": world * args.steps / dt,
+            "value": whole_job_value(world, args.steps, dt),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -233,7 +244,9 @@ def main():
                 "channels_per_gpu": 1, "frames_in_flight": 2, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "cghip_composite", "avg_kernel_ms": avg_kernel_ms,
+                         "kernel": "cghip_composite_fast<%d>" % scene["bits"] if args.workload in ("config3_16bit", "config3_8bit", "config1")
+                         else "cghip_composite<%d>" % scene["bits"],
+                         "avg_kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
             "end_to_end_fps": e2e,

@@ -75,16 +75,27 @@ DEV int imin(int a, int b) { return a < b ? a : b; }
 DEV int imax(int a, int b) { return a > b ? a : b; }
 DEV int iclamp(int v, int lo, int hi) { return imin(imax(v, lo), hi); }
 
+/* plane memory is hipMalloc'd global memory: say so, or the loads through pointers fetched from the op list
+ * compile to flat_load (generic address space), which also ties up the LDS/scalar wait counter */
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef const GLOBAL_AS uint8_t*  G8;
+typedef const GLOBAL_AS uint16_t* G16;
+typedef const GLOBAL_AS uint32_t* G32;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const GLOBAL_AS u32x2*    GU2;
+typedef const GLOBAL_AS u32x4*    GU4;
+
 /* 8-bit texel as a packed word in MEMORY channel order (byte k = k-th sample of the texel) */
 DEV uint32_t load8(const KPlane& p, int x, int y)
 {
     const size_t   idx = (size_t)y * (size_t)p.w + (size_t)x;
-    const uint8_t* b   = (const uint8_t*)p.ptr;
+    const G8       b   = (G8)p.ptr;
     switch (p.channels) {
         case 1: return b[idx];
-        case 2: return ((const uint16_t*)p.ptr)[idx];
+        case 2: return ((G16)p.ptr)[idx];
         case 3: return (uint32_t)b[idx * 3] | ((uint32_t)b[idx * 3 + 1] << 8) | ((uint32_t)b[idx * 3 + 2] << 16);
-        default: return ((const uint32_t*)p.ptr)[idx];
+        default: return ((G32)p.ptr)[idx];
     }
 }
 
@@ -135,19 +146,19 @@ DEV f4 sample8_fixed(const KPlane& p, int iu, int iv)
 DEV void load16(const KPlane& p, int x, int y, float m[4])
 {
     const size_t    idx = ((size_t)y * (size_t)p.w + (size_t)x) * (size_t)p.channels;
-    const uint16_t* s   = (const uint16_t*)p.ptr;
+    const G16       s   = (G16)p.ptr;
     const float     sc  = 1.0f / 65535.0f;
     m[0] = m[1] = m[2] = m[3] = 0.0f;
     switch (p.channels) {
         case 1: m[0] = (float)s[idx] * sc; break;
         case 2: {
-            uint32_t v = *(const uint32_t*)(s + idx);
+            uint32_t v = *(G32)(s + idx);
             m[0] = (float)(v & 0xffff) * sc, m[1] = (float)(v >> 16) * sc;
             break;
         }
         case 3: m[0] = (float)s[idx] * sc, m[1] = (float)s[idx + 1] * sc, m[2] = (float)s[idx + 2] * sc; break;
         default: {
-            uint2 v = *(const uint2*)(s + idx);
+            const u32x2 v = *(GU2)(s + idx);
             m[0] = (float)(v.x & 0xffff) * sc, m[1] = (float)(v.x >> 16) * sc;
             m[2] = (float)(v.y & 0xffff) * sc, m[3] = (float)(v.y >> 16) * sc;
         }
@@ -701,112 +712,177 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 DEV float lerpf(float a, float b, float w) { return a + w * (b - a); }
 DEV int   lerp8i(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); }
 
-/* Four horizontally adjacent samples of a 1-channel plane for output texels sx..sx+3 (sx % 4 == 0), at
- * unit scale (half == 0: texel = sx+i) or from a half-width plane (half == 1: texel centres fall at 1/4 and
- * 3/4 between neighbours, weights 0.75 / 0.25 exactly). Row r of the plane. Values are returned as the
- * floats texture() would give. 16-bit: fp32 lerp; 8-bit: rounded integer lerp with 8-bit weights. */
+struct Row3 {
+    uint32_t a, b, c;
+};
+
+/* Raw texels of one op for one lane's four pixels, as loaded (no conversion yet), so that ALL loads of an op
+ * are in flight before the first conversion waits for one (otherwise every plane costs its own HBM round trip). Everything here is passed BY VALUE: writing texels through
+ * references with constant offsets let the optimiser merge look-alike stores into stores through a phi of
+ * addresses, which pinned the whole record in scratch memory.
+ *   planar: y, a = full-width rows (2 dwords at 16 bit, 1 at 8 bit); cb0/cb1, cr0/cr1 = chroma rows, either
+ *           full-width or {aligned pair, left neighbour, right neighbour} of a half-width plane
+ *   packed: the 4 (8-bit) or 8 (16-bit) dwords of four BGRA texels in y, a, cb0 */
+struct Tex {
+    Row3 y, a, cb0, cb1, cr0, cr1;
+};
+
+/* loads of one plane row for four pixels */
 template <int SRC_BITS>
-DEV void row4(const KPlane& p, int r, int sx, int half, float o[4])
+DEV Row3 issue_row(const KPlane& p, int r, int sx, int half)
+{
+    Row3 o = {0, 0, 0};
+    if (SRC_BITS == 16) {
+        const G16 row = (G16)p.ptr + (size_t)r * (size_t)p.w;
+        if (!half) {
+            const u32x2 v = *(const GU2)(row + sx);
+            o.a = v.x, o.b = v.y;
+        } else {
+            const int k = sx >> 1;
+            o.a         = *(const G32)(row + k);
+            o.b         = row[imax(k - 1, 0)];
+            o.c         = row[imin(k + 2, p.w - 1)];
+        }
+    } else {
+        const G8 row = (G8)p.ptr + (size_t)r * (size_t)p.w;
+        if (!half) {
+            o.a = *(const G32)(row + sx);
+        } else {
+            const int k = sx >> 1;
+            o.a         = *(const G16)(row + k);
+            o.b         = row[imax(k - 1, 0)];
+            o.c         = row[imin(k + 2, p.w - 1)];
+        }
+    }
+    return o;
+}
+
+/* Four horizontally adjacent samples of a 1-channel plane row for output texels sx..sx+3 (sx % 4 == 0): at
+ * unit scale (half == 0) or from a half-width plane (half == 1: texel centres fall 1/4 and 3/4 between
+ * neighbours, weights 0.75 / 0.25 exactly). 16-bit: floats as texture() returns them, fp32 lerp. 8-bit:
+ * integers after the rounded 8-bit-weight lerp (normalised later, after the optional row lerp). */
+template <int SRC_BITS>
+DEV void convert_row(const Row3 r, int half, float o[4])
 {
     if (SRC_BITS == 16) {
-        const uint16_t* row = (const uint16_t*)p.ptr + (size_t)r * (size_t)p.w;
-        const float     sc  = 1.0f / 65535.0f;
+        const float sc = 1.0f / 65535.0f;
         if (!half) {
-            const uint2 v = *(const uint2*)(row + sx);
-            o[0] = (float)(v.x & 0xffff) * sc, o[1] = (float)(v.x >> 16) * sc;
-            o[2] = (float)(v.y & 0xffff) * sc, o[3] = (float)(v.y >> 16) * sc;
+            o[0] = (float)(r.a & 0xffff) * sc, o[1] = (float)(r.a >> 16) * sc;
+            o[2] = (float)(r.b & 0xffff) * sc, o[3] = (float)(r.b >> 16) * sc;
         } else {
-            const int      k  = sx >> 1;
-            const uint32_t m  = *(const uint32_t*)(row + k);
-            const float    t0 = (float)(m & 0xffff) * sc, t1 = (float)(m >> 16) * sc;
-            const float    tl = (float)row[imax(k - 1, 0)] * sc, tr = (float)row[imin(k + 2, p.w - 1)] * sc;
+            const float t0 = (float)(r.a & 0xffff) * sc, t1 = (float)(r.a >> 16) * sc;
+            const float tl = (float)r.b * sc, tr = (float)r.c * sc;
             o[0] = lerpf(tl, t0, 0.75f), o[1] = lerpf(t0, t1, 0.25f);
             o[2] = lerpf(t0, t1, 0.75f), o[3] = lerpf(t1, tr, 0.25f);
         }
     } else {
-        const uint8_t* row = (const uint8_t*)p.ptr + (size_t)r * (size_t)p.w;
-        int            q[4];
+        int q[4];
         if (!half) {
-            const uint32_t v = *(const uint32_t*)(row + sx);
-            q[0] = v & 0xff, q[1] = (v >> 8) & 0xff, q[2] = (v >> 16) & 0xff, q[3] = v >> 24;
+            q[0] = r.a & 0xff, q[1] = (r.a >> 8) & 0xff, q[2] = (r.a >> 16) & 0xff, q[3] = r.a >> 24;
         } else {
-            const int      k  = sx >> 1;
-            const uint32_t m  = *(const uint16_t*)(row + k);
-            const int      t0 = m & 0xff, t1 = m >> 8;
-            const int      tl = row[imax(k - 1, 0)], tr = row[imin(k + 2, p.w - 1)];
+            const int t0 = r.a & 0xff, t1 = (r.a >> 8) & 0xff, tl = (int)r.b, tr = (int)r.c;
             q[0] = lerp8i(tl, t0, 192), q[1] = lerp8i(t0, t1, 64);
             q[2] = lerp8i(t0, t1, 192), q[3] = lerp8i(t1, tr, 64);
         }
-        /* the integer results are returned un-normalised; plane4 scales after the optional row lerp */
         o[0] = (float)q[0], o[1] = (float)q[1], o[2] = (float)q[2], o[3] = (float)q[3];
     }
 }
 
-/* plane4: row4 plus the vertical half-resolution lerp (4:2:0), x first then y like the sampler. */
+/* chroma plane: one row, or two rows lerped vertically (4:2:0), x first then y like the sampler */
 template <int SRC_BITS>
-DEV void plane4(const KPlane& p, int sx, int sy, int halfx, int halfy, float o[4])
+DEV void convert_chroma(const Row3 t, const Row3 u, int sy, int halfx, int halfy, float o[4])
 {
-    if (!halfy) {
-        row4<SRC_BITS>(p, sy, sx, halfx, o);
-    } else {
+    float a[4], b[4];
+    convert_row<SRC_BITS>(t, halfx, a);
+    if (halfy) {
         /* v = (sy + .5)/2 - .5: even rows sit 3/4 of the way from row sy/2-1 to sy/2, odd rows 1/4 from (sy-1)/2 */
-        const int   r0 = (sy - 1) >> 1;
-        const bool  odd = sy & 1;
-        float       a[4], b[4];
-        row4<SRC_BITS>(p, iclamp(r0, 0, p.h - 1), sx, halfx, a);
-        row4<SRC_BITS>(p, iclamp(r0 + 1, 0, p.h - 1), sx, halfx, b);
+        const bool odd = sy & 1;
+        convert_row<SRC_BITS>(u, halfx, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (SRC_BITS == 16)
-                o[i] = lerpf(a[i], b[i], odd ? 0.25f : 0.75f);
+                a[i] = lerpf(a[i], b[i], odd ? 0.25f : 0.75f);
             else
-                o[i] = (float)lerp8i((int)a[i], (int)b[i], odd ? 64 : 192);
+                a[i] = (float)lerp8i((int)a[i], (int)b[i], odd ? 64 : 192);
         }
     }
-    if (SRC_BITS == 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            o[i] *= (1.0f / 255.0f);
-    }
+    for (int i = 0; i < 4; ++i)
+        o[i] = SRC_BITS == 8 ? a[i] * (1.0f / 255.0f) : a[i];
 }
 
-/* source colours of four adjacent pixels, FC_PLANAR / FC_PACKED ops (vector loads) */
+/* stage 1: put the op's loads in flight */
 template <int SRC_BITS>
-DEV void fetch4(const KOp& op, int sx, int sy, f4 col[4])
+DEV Tex issue_op(const KOp& op, int sx, int sy)
+{
+    const Row3 z = {0, 0, 0};
+    Row3       y = z, a = z, cb0 = z, cb1 = z, cr0 = z, cr1 = z;
+    if (op.fast_class == FC_PLANAR) {
+        const int halfx = op.csx, halfy = op.csy;
+        const int r0 = (sy - 1) >> 1;
+        const int ra = halfy ? iclamp(r0, 0, op.planes[1].h - 1) : sy;
+        const int rb = iclamp(r0 + 1, 0, op.planes[1].h - 1);
+        y            = issue_row<SRC_BITS>(op.planes[0], sy, sx, 0);
+        cb0          = issue_row<SRC_BITS>(op.planes[1], ra, sx, halfx);
+        cr0          = issue_row<SRC_BITS>(op.planes[2], ra, sx, halfx);
+        if (halfy) {
+            cb1 = issue_row<SRC_BITS>(op.planes[1], rb, sx, halfx);
+            cr1 = issue_row<SRC_BITS>(op.planes[2], rb, sx, halfx);
+        }
+        if (op.pixel_format == 6)
+            a = issue_row<SRC_BITS>(op.planes[3], sy, sx, 0);
+    } else {
+        const KPlane& p = op.planes[0];
+        if (SRC_BITS == 8) {
+            const u32x4 v = *(const GU4)((G32)p.ptr + (size_t)sy * (size_t)p.w + sx);
+            y = Row3{v.x, v.y, v.z};
+            a = Row3{v.w, 0, 0};
+        } else {
+            const GU4 src = (const GU4)((GU2)p.ptr + (size_t)sy * (size_t)p.w + sx);
+            const u32x4 v = src[0], w = src[1];
+            y   = Row3{v.x, v.y, v.z};
+            a   = Row3{v.w, w.x, w.y};
+            cb0 = Row3{w.z, w.w, 0};
+        }
+    }
+    return Tex{y, a, cb0, cb1, cr0, cr1};
+}
+
+/* stage 2: raw texels -> source colours of the four pixels */
+template <int SRC_BITS>
+DEV void convert_op(const KOp& op, const Tex t, int sy, f4 col[4])
 {
     if (op.fast_class == FC_PLANAR) {
         float Y[4], Cb[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        plane4<SRC_BITS>(op.planes[0], sx, sy, 0, 0, Y);
-        plane4<SRC_BITS>(op.planes[1], sx, sy, op.csx, op.csy, Cb);
-        plane4<SRC_BITS>(op.planes[2], sx, sy, op.csx, op.csy, Cr);
-        if (op.pixel_format == 6)
-            plane4<SRC_BITS>(op.planes[3], sx, sy, 0, 0, Al);
+        const float sc = SRC_BITS == 8 ? 1.0f / 255.0f : 1.0f;
+        convert_row<SRC_BITS>(t.y, 0, Y);
+        convert_chroma<SRC_BITS>(t.cb0, t.cb1, sy, op.csx, op.csy, Cb);
+        convert_chroma<SRC_BITS>(t.cr0, t.cr1, sy, op.csx, op.csy, Cr);
+        if (op.pixel_format == 6) {
+            convert_row<SRC_BITS>(t.a, 0, Al);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                Al[i] *= sc;
+        }
         const bool hd = op.flags & KF_IS_HD;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            col[i] = ycbcra_to_rgba(Y[i], Cb[i], Cr[i], Al[i], hd);
-    } else { /* FC_PACKED: one 4-channel plane */
-        const KPlane& p = op.planes[0];
-        if (SRC_BITS == 8) {
-            const uint4    v    = *(const uint4*)((const uint32_t*)p.ptr + (size_t)sy * (size_t)p.w + sx);
-            const uint32_t m[4] = {v.x, v.y, v.z, v.w};
-            const float    sc   = 1.0f / 255.0f;
+            col[i] = ycbcra_to_rgba(SRC_BITS == 8 ? Y[i] * sc : Y[i], Cb[i], Cr[i], Al[i], hd);
+    } else if (SRC_BITS == 8) {
+        const float    sc   = 1.0f / 255.0f;
+        const uint32_t m[4] = {t.y.a, t.y.b, t.y.c, t.a.a};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                col[i] = swizzle_format(op.pixel_format,
-                                        f4{(float)((m[i] >> 16) & 0xff) * sc, (float)((m[i] >> 8) & 0xff) * sc,
-                                           (float)(m[i] & 0xff) * sc, (float)(m[i] >> 24) * sc});
-        } else {
-            const uint4* src = (const uint4*)((const uint2*)p.ptr + (size_t)sy * (size_t)p.w + sx);
-            const uint4  a = src[0], b = src[1];
-            const uint32_t m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            const float    sc   = 1.0f / 65535.0f;
+        for (int i = 0; i < 4; ++i)
+            col[i] = swizzle_format(op.pixel_format, f4{(float)((m[i] >> 16) & 0xff) * sc, (float)((m[i] >> 8) & 0xff) * sc,
+                                                        (float)(m[i] & 0xff) * sc, (float)(m[i] >> 24) * sc});
+    } else {
+        const float    sc   = 1.0f / 65535.0f;
+        const uint32_t m[8] = {t.y.a, t.y.b, t.y.c, t.a.a, t.a.b, t.a.c, t.cb0.a, t.cb0.b};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                col[i] = swizzle_format(op.pixel_format,
-                                        f4{(float)(m[2 * i + 1] & 0xffff) * sc, (float)(m[2 * i] >> 16) * sc,
-                                           (float)(m[2 * i] & 0xffff) * sc, (float)(m[2 * i + 1] >> 16) * sc});
-        }
+        for (int i = 0; i < 4; ++i)
+            col[i] = swizzle_format(op.pixel_format,
+                                    f4{(float)(m[2 * i + 1] & 0xffff) * sc, (float)(m[2 * i] >> 16) * sc,
+                                       (float)(m[2 * i] & 0xffff) * sc, (float)(m[2 * i + 1] >> 16) * sc});
     }
 }
 
@@ -856,9 +932,9 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         const int sx = px0 + op.unit_dx, sy = y + op.unit_dy;
         f4        col[P];
         if (op.planes[0].bits == 16)
-            fetch4<16>(op, sx, sy, col);
+            convert_op<16>(op, issue_op<16>(op, sx, sy), sy, col);
         else
-            fetch4<8>(op, sx, sy, col);
+            convert_op<8>(op, issue_op<8>(op, sx, sy), sy, col);
         if (op.dst >= KS_KEY0) { /* key surface: only the red slot is stored (image_mixer.cpp:174-183) */
             const bool key1 = op.dst == KS_KEY1;
             static_for<0, P>([&](auto I) {
