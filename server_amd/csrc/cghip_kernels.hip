@@ -563,23 +563,26 @@ template <bool BLEND>
 DEV f4 shade_blend(const KOp& op, f4 color, float lkey, float ykey, f4 back)
 {
 #pragma clang fp contract(off)
-    if (op.local_key != KS_NONE)
-        color.x *= lkey, color.y *= lkey, color.z *= lkey, color.w *= lkey;
-    if (op.layer_key != KS_NONE)
-        color.x *= ykey, color.y *= ykey, color.z *= ykey, color.w *= ykey;
+    /* The optional steps are made unconditional with neutral operands instead of wave-uniform branches (which
+       the compiler turns into compute-both-and-select): x*1 == x, fma(x, 1, 0) == x and fma(x, -1, 1) == 1 - x
+       exactly, so the roundings are those of the shader's own sequence. */
+    const float k1 = op.local_key != KS_NONE ? lkey : 1.0f;
+    const float k2 = op.layer_key != KS_NONE ? ykey : 1.0f;
+    color.x *= k1, color.y *= k1, color.z *= k1, color.w *= k1;
+    color.x *= k2, color.y *= k2, color.z *= k2, color.w *= k2;
     color.x *= op.opacity, color.y *= op.opacity, color.z *= op.opacity, color.w *= op.opacity;
-    if (op.flags & KF_INVERT)
-        color = f4{1.0f - color.x, 1.0f - color.y, 1.0f - color.z, 1.0f - color.w};
-    f4 fore = color;
+    const bool  inv = op.flags & KF_INVERT;
+    const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
+    f4 fore = {__builtin_fmaf(color.x, im, ia0), __builtin_fmaf(color.y, im, ia0), __builtin_fmaf(color.z, im, ia0),
+               __builtin_fmaf(color.w, im, ia0)};
     if (BLEND && op.blend_mode != 0) { /* shader.frag:427-428 */
         const float ba = back.w + 0.0000001f, fa = fore.w + 0.0000001f;
         const f3    bc = get_blend_color(op.blend_mode, f3{fdiv(back.x, ba), fdiv(back.y, ba), fdiv(back.z, ba)},
                                       f3{fdiv(fore.x, fa), fdiv(fore.y, fa), fdiv(fore.z, fa)});
         fore.x = bc.x * fore.w, fore.y = bc.y * fore.w, fore.z = bc.z * fore.w;
     }
-    if (op.flags & KF_ADDITIVE) /* shader.frag:429-433 */
-        return f4{fore.x + back.x, fore.y + back.y, fore.z + back.z, fore.w + back.w};
-    const float ia = 1.0f - fore.w;
+    /* shader.frag:429-433: additive keyer = fore + back, linear = fore + (1 - fore.a) * back */
+    const float ia = (op.flags & KF_ADDITIVE) ? 1.0f : 1.0f - fore.w;
     return f4{fore.x + ia * back.x, fore.y + ia * back.y, fore.z + ia * back.z, fore.w + ia * back.w};
 }
 
@@ -917,18 +920,17 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
 
     for (int n = 0; n < nops && row_live; ++n) {
         const KOp& op = ops[n];
-        if (op.kind == KOP_CLEAR) {
-            static_for<0, P>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                K0[i] = op.dst == KS_KEY0 ? 0.0f : K0[i];
-                K1[i] = op.dst == KS_KEY1 ? 0.0f : K1[i];
-            });
+        const bool clr  = op.kind == KOP_CLEAR;
+        const bool clr0 = clr & (op.dst == KS_KEY0), clr1 = clr & (op.dst == KS_KEY1);
+        static_for<0, P>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            K0[i] = clr0 ? 0.0f : K0[i];
+            K1[i] = clr1 ? 0.0f : K1[i];
+        });
+        /* one combined test, one merge point: a chain of early `continue`s made the compiler copy all 24
+           loop-carried registers at every exit. op.x0, op.x1 are multiples of 4: a lane is all in or all out. */
+        if (clr | !((y >= op.y0) & (y < op.y1) & (px0 >= op.x0) & (px0 < op.x1)))
             continue;
-        }
-        if (y < op.y0 || y >= op.y1 || wave_x1 <= op.x0 || wave_x0 >= op.x1)
-            continue;
-        if (px0 < op.x0 || px0 >= op.x1)
-            continue; /* op.x0, op.x1 are multiples of 4: the lane is all in or all out */
         const int sx = px0 + op.unit_dx, sy = y + op.unit_dy;
         f4        col[P];
         if (op.planes[0].bits == 16)
