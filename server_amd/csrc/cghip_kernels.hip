@@ -712,32 +712,34 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 
 /* ------------------------------------------------------------------ the fast compositor */
 
+/* Fast compositor: frames whose every draw is a unit-scale, normal-blend layer whose pixel box and source offset
+ * are multiples of 4 pixels (full-screen video stacks with key layers, chroma key, levels, CSB: BASELINE configs
+ * 1, 3 and most of a live rundown). Four pixels per lane: a wave owns 256 consecutive pixels of a row, sources
+ * arrive through aligned 4..32-byte loads, the frame leaves through 16/32-byte stores; a lane is either wholly
+ * inside an op's box or wholly outside it, so there is no per-pixel predication. Numerics are those of
+ * cghip_composite.
+ *
+ * The kernel is VALU-issue bound, so the per-op code is organised as a few STRAIGHT-LINE bodies picked by
+ * wave-uniform tests (source layout x bit depth, then adjustments, then the blend variant) instead of per-pixel
+ * switches: every wave-uniform branch inside a per-pixel function became a thicket of blocks, selects and
+ * register copies. */
+
 DEV float lerpf(float a, float b, float w) { return a + w * (b - a); }
 DEV int   lerp8i(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); }
 
+/* raw texels of one plane row for a lane's four pixels: a, b = the row's dwords; half-width planes: a = the
+ * aligned texel pair, b / c = left / right neighbour texel (clamped to the edge) */
 struct Row3 {
     uint32_t a, b, c;
 };
 
-/* Raw texels of one op for one lane's four pixels, as loaded (no conversion yet), so that ALL loads of an op
- * are in flight before the first conversion waits for one (otherwise every plane costs its own HBM round trip). Everything here is passed BY VALUE: writing texels through
- * references with constant offsets let the optimiser merge look-alike stores into stores through a phi of
- * addresses, which pinned the whole record in scratch memory.
- *   planar: y, a = full-width rows (2 dwords at 16 bit, 1 at 8 bit); cb0/cb1, cr0/cr1 = chroma rows, either
- *           full-width or {aligned pair, left neighbour, right neighbour} of a half-width plane
- *   packed: the 4 (8-bit) or 8 (16-bit) dwords of four BGRA texels in y, a, cb0 */
-struct Tex {
-    Row3 y, a, cb0, cb1, cr0, cr1;
-};
-
-/* loads of one plane row for four pixels */
-template <int SRC_BITS>
-DEV Row3 issue_row(const KPlane& p, int r, int sx, int half)
+template <int SB, int HALF>
+DEV Row3 load_row(const KPlane& p, int r, int sx)
 {
     Row3 o = {0, 0, 0};
-    if (SRC_BITS == 16) {
+    if (SB == 16) {
         const G16 row = (G16)p.ptr + (size_t)r * (size_t)p.w;
-        if (!half) {
+        if (!HALF) {
             const u32x2 v = *(const GU2)(row + sx);
             o.a = v.x, o.b = v.y;
         } else {
@@ -748,7 +750,7 @@ DEV Row3 issue_row(const KPlane& p, int r, int sx, int half)
         }
     } else {
         const G8 row = (G8)p.ptr + (size_t)r * (size_t)p.w;
-        if (!half) {
+        if (!HALF) {
             o.a = *(const G32)(row + sx);
         } else {
             const int k = sx >> 1;
@@ -761,15 +763,15 @@ DEV Row3 issue_row(const KPlane& p, int r, int sx, int half)
 }
 
 /* Four horizontally adjacent samples of a 1-channel plane row for output texels sx..sx+3 (sx % 4 == 0): at
- * unit scale (half == 0) or from a half-width plane (half == 1: texel centres fall 1/4 and 3/4 between
+ * unit scale (HALF == 0) or from a half-width plane (HALF == 1: texel centres fall 1/4 and 3/4 between
  * neighbours, weights 0.75 / 0.25 exactly). 16-bit: floats as texture() returns them, fp32 lerp. 8-bit:
- * integers after the rounded 8-bit-weight lerp (normalised later, after the optional row lerp). */
-template <int SRC_BITS>
-DEV void convert_row(const Row3 r, int half, float o[4])
+ * integer codes after the rounded 8-bit-weight lerp, as floats (normalised later, after the optional row lerp). */
+template <int SB, int HALF>
+DEV void convert_row(const Row3 r, float o[4])
 {
-    if (SRC_BITS == 16) {
+    if (SB == 16) {
         const float sc = 1.0f / 65535.0f;
-        if (!half) {
+        if (!HALF) {
             o[0] = (float)(r.a & 0xffff) * sc, o[1] = (float)(r.a >> 16) * sc;
             o[2] = (float)(r.b & 0xffff) * sc, o[3] = (float)(r.b >> 16) * sc;
         } else {
@@ -779,31 +781,31 @@ DEV void convert_row(const Row3 r, int half, float o[4])
             o[2] = lerpf(t0, t1, 0.75f), o[3] = lerpf(t1, tr, 0.25f);
         }
     } else {
-        int q[4];
-        if (!half) {
-            q[0] = r.a & 0xff, q[1] = (r.a >> 8) & 0xff, q[2] = (r.a >> 16) & 0xff, q[3] = r.a >> 24;
+        if (!HALF) {
+            o[0] = (float)(r.a & 0xff), o[1] = (float)((r.a >> 8) & 0xff);
+            o[2] = (float)((r.a >> 16) & 0xff), o[3] = (float)(r.a >> 24);
         } else {
             const int t0 = r.a & 0xff, t1 = (r.a >> 8) & 0xff, tl = (int)r.b, tr = (int)r.c;
-            q[0] = lerp8i(tl, t0, 192), q[1] = lerp8i(t0, t1, 64);
-            q[2] = lerp8i(t0, t1, 192), q[3] = lerp8i(t1, tr, 64);
+            o[0] = (float)lerp8i(tl, t0, 192), o[1] = (float)lerp8i(t0, t1, 64);
+            o[2] = (float)lerp8i(t0, t1, 192), o[3] = (float)lerp8i(t1, tr, 64);
         }
-        o[0] = (float)q[0], o[1] = (float)q[1], o[2] = (float)q[2], o[3] = (float)q[3];
     }
 }
 
-/* chroma plane: one row, or two rows lerped vertically (4:2:0), x first then y like the sampler */
-template <int SRC_BITS>
-DEV void convert_chroma(const Row3 t, const Row3 u, int sy, int halfx, int halfy, float o[4])
+/* chroma plane: one row, or two rows lerped vertically (4:2:0), x first then y like the sampler; normalised */
+template <int SB, int HX, int HY>
+DEV void convert_chroma(const Row3 t, const Row3 u, int sy, float o[4])
 {
-    float a[4], b[4];
-    convert_row<SRC_BITS>(t, halfx, a);
-    if (halfy) {
+    float a[4];
+    convert_row<SB, HX>(t, a);
+    if (HY) {
         /* v = (sy + .5)/2 - .5: even rows sit 3/4 of the way from row sy/2-1 to sy/2, odd rows 1/4 from (sy-1)/2 */
         const bool odd = sy & 1;
-        convert_row<SRC_BITS>(u, halfx, b);
+        float      b[4];
+        convert_row<SB, HX>(u, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (SRC_BITS == 16)
+            if (SB == 16)
                 a[i] = lerpf(a[i], b[i], odd ? 0.25f : 0.75f);
             else
                 a[i] = (float)lerp8i((int)a[i], (int)b[i], odd ? 64 : 192);
@@ -811,90 +813,162 @@ DEV void convert_chroma(const Row3 t, const Row3 u, int sy, int halfx, int halfy
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        o[i] = SRC_BITS == 8 ? a[i] * (1.0f / 255.0f) : a[i];
+        o[i] = SB == 8 ? a[i] * (1.0f / 255.0f) : a[i];
 }
 
-/* stage 1: put the op's loads in flight */
-template <int SRC_BITS>
-DEV Tex issue_op(const KOp& op, int sx, int sy)
+/* source colours of four pixels from ycbcr / ycbcra planes (shader.frag:441-467,500-512) */
+template <int SB, int HX, int HY>
+DEV void fetch_planar(const KOp& op, int sx, int sy, f4 col[4])
 {
-    const Row3 z = {0, 0, 0};
-    Row3       y = z, a = z, cb0 = z, cb1 = z, cr0 = z, cr1 = z;
-    if (op.fast_class == FC_PLANAR) {
-        const int halfx = op.csx, halfy = op.csy;
-        const int r0 = (sy - 1) >> 1;
-        const int ra = halfy ? iclamp(r0, 0, op.planes[1].h - 1) : sy;
-        const int rb = iclamp(r0 + 1, 0, op.planes[1].h - 1);
-        y            = issue_row<SRC_BITS>(op.planes[0], sy, sx, 0);
-        cb0          = issue_row<SRC_BITS>(op.planes[1], ra, sx, halfx);
-        cr0          = issue_row<SRC_BITS>(op.planes[2], ra, sx, halfx);
-        if (halfy) {
-            cb1 = issue_row<SRC_BITS>(op.planes[1], rb, sx, halfx);
-            cr1 = issue_row<SRC_BITS>(op.planes[2], rb, sx, halfx);
-        }
-        if (op.pixel_format == 6)
-            a = issue_row<SRC_BITS>(op.planes[3], sy, sx, 0);
-    } else {
-        const KPlane& p = op.planes[0];
-        if (SRC_BITS == 8) {
-            const u32x4 v = *(const GU4)((G32)p.ptr + (size_t)sy * (size_t)p.w + sx);
-            y = Row3{v.x, v.y, v.z};
-            a = Row3{v.w, 0, 0};
-        } else {
-            const GU4 src = (const GU4)((GU2)p.ptr + (size_t)sy * (size_t)p.w + sx);
-            const u32x4 v = src[0], w = src[1];
-            y   = Row3{v.x, v.y, v.z};
-            a   = Row3{v.w, w.x, w.y};
-            cb0 = Row3{w.z, w.w, 0};
-        }
+    const int  r0    = (sy - 1) >> 1;
+    const int  ra    = HY ? iclamp(r0, 0, op.planes[1].h - 1) : sy;
+    const int  rb    = HY ? iclamp(r0 + 1, 0, op.planes[1].h - 1) : sy;
+    const bool alpha = op.pixel_format == 6;
+    /* all loads first: one HBM round trip per op, not one per plane */
+    const Row3 y   = load_row<SB, 0>(op.planes[0], sy, sx);
+    const Row3 cb0 = load_row<SB, HX>(op.planes[1], ra, sx);
+    const Row3 cr0 = load_row<SB, HX>(op.planes[2], ra, sx);
+    Row3       cb1 = {0, 0, 0}, cr1 = {0, 0, 0}, al = {0, 0, 0};
+    if (HY) {
+        cb1 = load_row<SB, HX>(op.planes[1], rb, sx);
+        cr1 = load_row<SB, HX>(op.planes[2], rb, sx);
     }
-    return Tex{y, a, cb0, cb1, cr0, cr1};
-}
+    if (alpha)
+        al = load_row<SB, 0>(op.planes[3], sy, sx);
 
-/* stage 2: raw texels -> source colours of the four pixels */
-template <int SRC_BITS>
-DEV void convert_op(const KOp& op, const Tex t, int sy, f4 col[4])
-{
-    if (op.fast_class == FC_PLANAR) {
-        float Y[4], Cb[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        const float sc = SRC_BITS == 8 ? 1.0f / 255.0f : 1.0f;
-        convert_row<SRC_BITS>(t.y, 0, Y);
-        convert_chroma<SRC_BITS>(t.cb0, t.cb1, sy, op.csx, op.csy, Cb);
-        convert_chroma<SRC_BITS>(t.cr0, t.cr1, sy, op.csx, op.csy, Cr);
-        if (op.pixel_format == 6) {
-            convert_row<SRC_BITS>(t.a, 0, Al);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                Al[i] *= sc;
-        }
-        const bool hd = op.flags & KF_IS_HD;
+    const float sc = SB == 8 ? 1.0f / 255.0f : 1.0f;
+    float       Y[4], Cb[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    convert_row<SB, 0>(y, Y);
+    convert_chroma<SB, HX, HY>(cb0, cb1, sy, Cb);
+    convert_chroma<SB, HX, HY>(cr0, cr1, sy, Cr);
+    if (alpha) {
+        convert_row<SB, 0>(al, Al);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            col[i] = ycbcra_to_rgba(SRC_BITS == 8 ? Y[i] * sc : Y[i], Cb[i], Cr[i], Al[i], hd);
-    } else if (SRC_BITS == 8) {
+            Al[i] *= sc;
+    }
+    /* coefficients picked by scalar selects: same arithmetic as ycbcra_to_rgba() */
+    const bool  hd  = op.flags & KF_IS_HD;
+    const float krr = hd ? 1.793f : 1.596f, kgr = hd ? 0.534f : 0.813f, kgb = hd ? 0.213f : 0.391f,
+                kbb = hd ? 2.115f : 2.018f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float yy = 1.164f * ((SB == 8 ? Y[i] * sc : Y[i]) * 255.0f - 16.0f);
+        const float cb = Cb[i] * 255.0f - 128.0f, cr = Cr[i] * 255.0f - 128.0f;
+        col[i].z       = div_const((yy + krr * cr), 255.0f, 1.0f / 255.0f);
+        col[i].y       = div_const((yy - kgr * cr - kgb * cb), 255.0f, 1.0f / 255.0f);
+        col[i].x       = div_const((yy + kbb * cb), 255.0f, 1.0f / 255.0f);
+        col[i].w       = Al[i];
+    }
+}
+
+/* source colours of four pixels from one 4-channel plane (bgra / rgba / argb / abgr, shader.frag:487-498). The
+ * format swizzle is a byte permute of the raw texel (selector picked by scalar selects), so the conversion that
+ * follows is the same straight line for all four formats. Internal order x,y,z,w = memory samples
+ * (0,1,2,3) for bgra, (2,1,0,3) rgba, (3,2,1,0) argb, (1,0,3,2) abgr. */
+template <int SB>
+DEV void fetch_packed(const KOp& op, int sx, int sy, f4 col[4])
+{
+    const KPlane& p  = op.planes[0];
+    const int     pf = op.pixel_format;
+    if (SB == 8) {
+        const uint32_t sel  = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
+        const u32x4    v    = *(const GU4)((G32)p.ptr + (size_t)sy * (size_t)p.w + sx);
+        const uint32_t m[4] = {v.x, v.y, v.z, v.w};
         const float    sc   = 1.0f / 255.0f;
-        const uint32_t m[4] = {t.y.a, t.y.b, t.y.c, t.a.a};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            col[i] = swizzle_format(op.pixel_format, f4{(float)((m[i] >> 16) & 0xff) * sc, (float)((m[i] >> 8) & 0xff) * sc,
-                                                        (float)(m[i] & 0xff) * sc, (float)(m[i] >> 24) * sc});
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t = __builtin_amdgcn_perm(m[i], m[i], sel);
+            col[i] = f4{(float)(t & 0xff) * sc, (float)((t >> 8) & 0xff) * sc, (float)((t >> 16) & 0xff) * sc,
+                        (float)(t >> 24) * sc};
+        }
     } else {
+        const uint32_t slo = pf == 1 ? 0x03020100u : pf == 2 ? 0x03020504u : pf == 3 ? 0x05040706u : 0x01000302u;
+        const uint32_t shi = pf == 1 ? 0x07060504u : pf == 2 ? 0x07060100u : pf == 3 ? 0x01000302u : 0x05040706u;
+        const GU4      src = (const GU4)((GU2)p.ptr + (size_t)sy * (size_t)p.w + sx);
+        const u32x4    v = src[0], w = src[1];
+        const uint32_t m[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
         const float    sc   = 1.0f / 65535.0f;
-        const uint32_t m[8] = {t.y.a, t.y.b, t.y.c, t.a.a, t.a.b, t.a.c, t.cb0.a, t.cb0.b};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            col[i] = swizzle_format(op.pixel_format,
-                                    f4{(float)(m[2 * i + 1] & 0xffff) * sc, (float)(m[2 * i] >> 16) * sc,
-                                       (float)(m[2 * i] & 0xffff) * sc, (float)(m[2 * i + 1] >> 16) * sc});
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], slo);
+            const uint32_t hi = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], shi);
+            col[i] = f4{(float)(lo & 0xffff) * sc, (float)(lo >> 16) * sc, (float)(hi & 0xffff) * sc,
+                        (float)(hi >> 16) * sc};
+        }
     }
 }
 
-/* Fast compositor: frames whose every draw is a unit-scale, normal-blend layer whose pixel box and source offset
- * are multiples of 4 pixels (full-screen video stacks with key layers, chroma key, levels, CSB: BASELINE configs
- * 1, 3 and most of a live rundown). Four pixels per lane: a wave owns 256 consecutive pixels of a row, sources
- * arrive through aligned 4..32-byte loads, the frame leaves through 16/32-byte stores; a lane is either wholly
- * inside an op's box or wholly outside it, so there is no per-pixel predication. Numerics are those of
- * cghip_composite. */
+/* shader.frag:532-541 for four pixels onto the RGBA target. SIMPLE: no keys, no invert, linear keyer: the
+ * neutral-operand steps of shade_blend() dropped (x*1, fma(x,1,0) are exact, so the results are the same). */
+template <int BITS, bool SIMPLE>
+DEV void blend_rgba4(const KOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
+{
+#pragma clang fp contract(off)
+    const float opa = op.opacity;
+    if (SIMPLE) {
+        static_for<0, 4>([&](auto I) {
+            constexpr int i  = decltype(I)::value;
+            const f4      f  = {col[i].x * opa, col[i].y * opa, col[i].z * opa, col[i].w * opa};
+            const float   ia = 1.0f - f.w;
+            S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
+                      quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
+        });
+    } else {
+        const bool  lk = op.local_key != KS_NONE, yk = op.layer_key != KS_NONE;
+        const bool  l1 = op.local_key == KS_KEY1, y1 = op.layer_key == KS_KEY1;
+        const bool  inv = op.flags & KF_INVERT, add = op.flags & KF_ADDITIVE;
+        const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
+        static_for<0, 4>([&](auto I) {
+            constexpr int i  = decltype(I)::value;
+            const float   k1 = lk ? (l1 ? K1[i] : K0[i]) : 1.0f;
+            const float   k2 = yk ? (y1 ? K1[i] : K0[i]) : 1.0f;
+            f4            c  = col[i];
+            c.x *= k1, c.y *= k1, c.z *= k1, c.w *= k1;
+            c.x *= k2, c.y *= k2, c.z *= k2, c.w *= k2;
+            c.x *= opa, c.y *= opa, c.z *= opa, c.w *= opa;
+            const f4    f  = {__builtin_fmaf(c.x, im, ia0), __builtin_fmaf(c.y, im, ia0), __builtin_fmaf(c.z, im, ia0),
+                              __builtin_fmaf(c.w, im, ia0)};
+            const float ia = add ? 1.0f : 1.0f - f.w;
+            S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
+                      quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
+        });
+    }
+}
+
+/* same onto a key surface: only the red slot is stored (image_mixer.cpp:174-183), so only red and alpha are
+ * evaluated. Keys of a key draw, if any, come from KEY0 like in cghip_composite. */
+template <int BITS, bool SIMPLE>
+DEV void blend_key4(const KOp& op, const f4 col[4], float K0[4], float K1[4])
+{
+#pragma clang fp contract(off)
+    const float opa  = op.opacity;
+    const bool  key1 = op.dst == KS_KEY1;
+    const bool  lk = op.local_key != KS_NONE, yk = op.layer_key != KS_NONE;
+    const bool  inv = op.flags & KF_INVERT, add = op.flags & KF_ADDITIVE;
+    const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
+    static_for<0, 4>([&](auto I) {
+        constexpr int i  = decltype(I)::value;
+        const float   a0 = K0[i], a1 = K1[i];
+        const float   back = key1 ? a1 : a0;
+        float         z = col[i].z, w = col[i].w, ia;
+        if (SIMPLE) {
+            z *= opa, w *= opa;
+            ia = 1.0f - w;
+        } else {
+            const float k1 = lk ? a0 : 1.0f, k2 = yk ? a0 : 1.0f;
+            z *= k1, w *= k1;
+            z *= k2, w *= k2;
+            z *= opa, w *= opa;
+            z  = __builtin_fmaf(z, im, ia0), w = __builtin_fmaf(w, im, ia0);
+            ia = add ? 1.0f : 1.0f - w;
+        }
+        const float q = quantize<BITS>(z + ia * back);
+        K0[i]         = key1 ? a0 : q;
+        K1[i]         = key1 ? q : a1;
+    });
+}
+
 template <int BITS>
 __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
                                                             int W, int H, int field_mode)
@@ -905,9 +979,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     const int     y    = blockIdx.y * 4 + wave;
     if (y >= H)
         return;
-    const int wave_x0 = blockIdx.x * 64 * P;
-    const int wave_x1 = wave_x0 + 64 * P;
-    const int px0     = wave_x0 + lane * P;
+    const int px0 = blockIdx.x * 64 * P + lane * P;
 
     f4    S[P];
     float K0[P], K1[P];
@@ -919,7 +991,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
     for (int n = 0; n < nops && row_live; ++n) {
-        const KOp& op = ops[n];
+        const KOp& op   = ops[n];
         const bool clr  = op.kind == KOP_CLEAR;
         const bool clr0 = clr & (op.dst == KS_KEY0), clr1 = clr & (op.dst == KS_KEY1);
         static_for<0, P>([&](auto I) {
@@ -931,31 +1003,51 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
            loop-carried registers at every exit. op.x0, op.x1 are multiples of 4: a lane is all in or all out. */
         if (clr | !((y >= op.y0) & (y < op.y1) & (px0 >= op.x0) & (px0 < op.x1)))
             continue;
-        const int sx = px0 + op.unit_dx, sy = y + op.unit_dy;
-        f4        col[P];
-        if (op.planes[0].bits == 16)
-            convert_op<16>(op, issue_op<16>(op, sx, sy), sy, col);
-        else
-            convert_op<8>(op, issue_op<8>(op, sx, sy), sy, col);
-        if (op.dst >= KS_KEY0) { /* key surface: only the red slot is stored (image_mixer.cpp:174-183) */
-            const bool key1 = op.dst == KS_KEY1;
-            static_for<0, P>([&](auto I) {
-                constexpr int i  = decltype(I)::value;
-                const float   a0 = K0[i], a1 = K1[i];
-                const f4      r  = shade<false>(op, col[i], a0, a0, f4{0.0f, 0.0f, key1 ? a1 : a0, 1.0f});
-                const float   q  = quantize<BITS>(r.z);
-                K0[i]            = key1 ? a0 : q;
-                K1[i]            = key1 ? q : a1;
-            });
+        const int  sx = px0 + op.unit_dx, sy = y + op.unit_dy;
+        const bool s16 = op.planes[0].bits == 16;
+        f4         col[P];
+        if (op.fast_class == FC_PACKED) {
+            if (s16)
+                fetch_packed<16>(op, sx, sy, col);
+            else
+                fetch_packed<8>(op, sx, sy, col);
         } else {
+            switch ((s16 ? 4 : 0) + op.csx + 2 * op.csy) {
+                case 0: fetch_planar<8, 0, 0>(op, sx, sy, col); break;
+                case 1: fetch_planar<8, 1, 0>(op, sx, sy, col); break;
+                case 2: fetch_planar<8, 0, 1>(op, sx, sy, col); break;
+                case 3: fetch_planar<8, 1, 1>(op, sx, sy, col); break;
+                case 4: fetch_planar<16, 0, 0>(op, sx, sy, col); break;
+                case 5: fetch_planar<16, 1, 0>(op, sx, sy, col); break;
+                case 6: fetch_planar<16, 0, 1>(op, sx, sy, col); break;
+                default: fetch_planar<16, 1, 1>(op, sx, sy, col); break;
+            }
+        }
+        /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
+        if (op.flags & KF_CHROMA) {
+            static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key(col[decltype(I)::value], op); });
+        }
+        if (op.flags & KF_LEVELS) {
             static_for<0, P>([&](auto I) {
-                constexpr int i    = decltype(I)::value;
-                const float   a0   = K0[i], a1 = K1[i];
-                const float   lkey = op.local_key == KS_KEY1 ? a1 : a0;
-                const float   ykey = op.layer_key == KS_KEY1 ? a1 : a0;
-                const f4      r    = shade<false>(op, col[i], lkey, ykey, S[i]);
-                S[i] = f4{quantize<BITS>(r.x), quantize<BITS>(r.y), quantize<BITS>(r.z), quantize<BITS>(r.w)};
+                constexpr int i = decltype(I)::value;
+                col[i].x = levels1(col[i].x, op), col[i].y = levels1(col[i].y, op), col[i].z = levels1(col[i].z, op);
             });
+        }
+        if (op.flags & KF_CSB) {
+            static_for<0, P>([&](auto I) { csb(col[decltype(I)::value], op); });
+        }
+        const bool simple =
+            op.local_key == KS_NONE && op.layer_key == KS_NONE && !(op.flags & (KF_INVERT | KF_ADDITIVE));
+        if (op.dst >= KS_KEY0) {
+            if (simple)
+                blend_key4<BITS, true>(op, col, K0, K1);
+            else
+                blend_key4<BITS, false>(op, col, K0, K1);
+        } else {
+            if (simple)
+                blend_rgba4<BITS, true>(op, col, S, K0, K1);
+            else
+                blend_rgba4<BITS, false>(op, col, S, K0, K1);
         }
     }
 
