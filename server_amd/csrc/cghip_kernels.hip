@@ -727,6 +727,37 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 DEV float lerpf(float a, float b, float w) { return a + w * (b - a); }
 DEV int   lerp8i(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); }
 
+/* The fields of an op that every fast-path draw needs, fetched together at the top of the op loop. Left to
+ * itself the compiler loads each KOp field in the block that first uses it, and every such block then starts
+ * with its own scalar-cache round trip (s_load + s_waitcnt): about ten serial stalls per op and wave. The empty
+ * asm pins the values in SGPRs right here, so all of the loads are issued back to back and waited for once.
+ * Adjustment parameters (levels, CSB, chroma key) stay lazily loaded inside their wave-uniform branches. */
+struct HotOp {
+    int32_t  kind;
+    uint32_t flags;
+    int32_t  dst, local_key, layer_key, pixel_format;
+    int32_t  x0, y0, x1, y1, unit_dx, unit_dy;
+    float    opacity;
+    int32_t  fast_class, csx, csy, bits0;
+    uint64_t ptr0, ptr1, ptr2, ptr3;
+    int32_t  w0, w1, w2, w3, h1;
+};
+
+DEV HotOp load_hot(const KOp& op)
+{
+    HotOp h = {op.kind, op.flags, op.dst, op.local_key, op.layer_key, op.pixel_format, op.x0, op.y0, op.x1, op.y1,
+               op.unit_dx, op.unit_dy, op.opacity, op.fast_class, op.csx, op.csy, op.planes[0].bits,
+               (uint64_t)op.planes[0].ptr, (uint64_t)op.planes[1].ptr, (uint64_t)op.planes[2].ptr,
+               (uint64_t)op.planes[3].ptr, op.planes[0].w, op.planes[1].w, op.planes[2].w, op.planes[3].w,
+               op.planes[1].h};
+    asm volatile(""
+                 : "+s"(h.kind), "+s"(h.flags), "+s"(h.dst), "+s"(h.local_key), "+s"(h.layer_key), "+s"(h.pixel_format),
+                   "+s"(h.x0), "+s"(h.y0), "+s"(h.x1), "+s"(h.y1), "+s"(h.unit_dx), "+s"(h.unit_dy), "+s"(h.opacity),
+                   "+s"(h.fast_class), "+s"(h.csx), "+s"(h.csy), "+s"(h.bits0), "+s"(h.ptr0), "+s"(h.ptr1),
+                   "+s"(h.ptr2), "+s"(h.ptr3), "+s"(h.w0), "+s"(h.w1), "+s"(h.w2), "+s"(h.w3), "+s"(h.h1));
+    return h;
+}
+
 /* raw texels of one plane row for a lane's four pixels: a, b = the row's dwords; half-width planes: a = the
  * aligned texel pair, b / c = left / right neighbour texel (clamped to the edge) */
 struct Row3 {
@@ -734,11 +765,11 @@ struct Row3 {
 };
 
 template <int SB, int HALF>
-DEV Row3 load_row(const KPlane& p, int r, int sx)
+DEV Row3 load_row(uint64_t ptr, int w, int r, int sx)
 {
     Row3 o = {0, 0, 0};
     if (SB == 16) {
-        const G16 row = (G16)p.ptr + (size_t)r * (size_t)p.w;
+        const G16 row = (G16)ptr + (size_t)r * (size_t)w;
         if (!HALF) {
             const u32x2 v = *(const GU2)(row + sx);
             o.a = v.x, o.b = v.y;
@@ -746,17 +777,17 @@ DEV Row3 load_row(const KPlane& p, int r, int sx)
             const int k = sx >> 1;
             o.a         = *(const G32)(row + k);
             o.b         = row[imax(k - 1, 0)];
-            o.c         = row[imin(k + 2, p.w - 1)];
+            o.c         = row[imin(k + 2, w - 1)];
         }
     } else {
-        const G8 row = (G8)p.ptr + (size_t)r * (size_t)p.w;
+        const G8 row = (G8)ptr + (size_t)r * (size_t)w;
         if (!HALF) {
             o.a = *(const G32)(row + sx);
         } else {
             const int k = sx >> 1;
             o.a         = *(const G16)(row + k);
             o.b         = row[imax(k - 1, 0)];
-            o.c         = row[imin(k + 2, p.w - 1)];
+            o.c         = row[imin(k + 2, w - 1)];
         }
     }
     return o;
@@ -818,23 +849,23 @@ DEV void convert_chroma(const Row3 t, const Row3 u, int sy, float o[4])
 
 /* source colours of four pixels from ycbcr / ycbcra planes (shader.frag:441-467,500-512) */
 template <int SB, int HX, int HY>
-DEV void fetch_planar(const KOp& op, int sx, int sy, f4 col[4])
+DEV void fetch_planar(const HotOp& op, int sx, int sy, f4 col[4])
 {
     const int  r0    = (sy - 1) >> 1;
-    const int  ra    = HY ? iclamp(r0, 0, op.planes[1].h - 1) : sy;
-    const int  rb    = HY ? iclamp(r0 + 1, 0, op.planes[1].h - 1) : sy;
+    const int  ra    = HY ? iclamp(r0, 0, op.h1 - 1) : sy;
+    const int  rb    = HY ? iclamp(r0 + 1, 0, op.h1 - 1) : sy;
     const bool alpha = op.pixel_format == 6;
     /* all loads first: one HBM round trip per op, not one per plane */
-    const Row3 y   = load_row<SB, 0>(op.planes[0], sy, sx);
-    const Row3 cb0 = load_row<SB, HX>(op.planes[1], ra, sx);
-    const Row3 cr0 = load_row<SB, HX>(op.planes[2], ra, sx);
+    const Row3 y   = load_row<SB, 0>(op.ptr0, op.w0, sy, sx);
+    const Row3 cb0 = load_row<SB, HX>(op.ptr1, op.w1, ra, sx);
+    const Row3 cr0 = load_row<SB, HX>(op.ptr2, op.w2, ra, sx);
     Row3       cb1 = {0, 0, 0}, cr1 = {0, 0, 0}, al = {0, 0, 0};
     if (HY) {
-        cb1 = load_row<SB, HX>(op.planes[1], rb, sx);
-        cr1 = load_row<SB, HX>(op.planes[2], rb, sx);
+        cb1 = load_row<SB, HX>(op.ptr1, op.w1, rb, sx);
+        cr1 = load_row<SB, HX>(op.ptr2, op.w2, rb, sx);
     }
     if (alpha)
-        al = load_row<SB, 0>(op.planes[3], sy, sx);
+        al = load_row<SB, 0>(op.ptr3, op.w3, sy, sx);
 
     const float sc = SB == 8 ? 1.0f / 255.0f : 1.0f;
     float       Y[4], Cb[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -867,13 +898,12 @@ DEV void fetch_planar(const KOp& op, int sx, int sy, f4 col[4])
  * follows is the same straight line for all four formats. Internal order x,y,z,w = memory samples
  * (0,1,2,3) for bgra, (2,1,0,3) rgba, (3,2,1,0) argb, (1,0,3,2) abgr. */
 template <int SB>
-DEV void fetch_packed(const KOp& op, int sx, int sy, f4 col[4])
+DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
 {
-    const KPlane& p  = op.planes[0];
-    const int     pf = op.pixel_format;
+    const int pf = op.pixel_format;
     if (SB == 8) {
         const uint32_t sel  = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
-        const u32x4    v    = *(const GU4)((G32)p.ptr + (size_t)sy * (size_t)p.w + sx);
+        const u32x4    v    = *(const GU4)((G32)op.ptr0 + (size_t)sy * (size_t)op.w0 + sx);
         const uint32_t m[4] = {v.x, v.y, v.z, v.w};
         const float    sc   = 1.0f / 255.0f;
 #pragma unroll
@@ -885,7 +915,7 @@ DEV void fetch_packed(const KOp& op, int sx, int sy, f4 col[4])
     } else {
         const uint32_t slo = pf == 1 ? 0x03020100u : pf == 2 ? 0x03020504u : pf == 3 ? 0x05040706u : 0x01000302u;
         const uint32_t shi = pf == 1 ? 0x07060504u : pf == 2 ? 0x07060100u : pf == 3 ? 0x01000302u : 0x05040706u;
-        const GU4      src = (const GU4)((GU2)p.ptr + (size_t)sy * (size_t)p.w + sx);
+        const GU4      src = (const GU4)((GU2)op.ptr0 + (size_t)sy * (size_t)op.w0 + sx);
         const u32x4    v = src[0], w = src[1];
         const uint32_t m[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
         const float    sc   = 1.0f / 65535.0f;
@@ -902,7 +932,7 @@ DEV void fetch_packed(const KOp& op, int sx, int sy, f4 col[4])
 /* shader.frag:532-541 for four pixels onto the RGBA target. SIMPLE: no keys, no invert, linear keyer: the
  * neutral-operand steps of shade_blend() dropped (x*1, fma(x,1,0) are exact, so the results are the same). */
 template <int BITS, bool SIMPLE>
-DEV void blend_rgba4(const KOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
+DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
 {
 #pragma clang fp contract(off)
     const float opa = op.opacity;
@@ -939,7 +969,7 @@ DEV void blend_rgba4(const KOp& op, const f4 col[4], f4 S[4], const float K0[4],
 /* same onto a key surface: only the red slot is stored (image_mixer.cpp:174-183), so only red and alpha are
  * evaluated. Keys of a key draw, if any, come from KEY0 like in cghip_composite. */
 template <int BITS, bool SIMPLE>
-DEV void blend_key4(const KOp& op, const f4 col[4], float K0[4], float K1[4])
+DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
 {
 #pragma clang fp contract(off)
     const float opa  = op.opacity;
@@ -991,63 +1021,63 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
     for (int n = 0; n < nops && row_live; ++n) {
-        const KOp& op   = ops[n];
-        const bool clr  = op.kind == KOP_CLEAR;
-        const bool clr0 = clr & (op.dst == KS_KEY0), clr1 = clr & (op.dst == KS_KEY1);
+        const KOp&  op  = ops[n];
+        const HotOp h   = load_hot(op);
+        const bool  clr = h.kind == KOP_CLEAR;
+        const bool  clr0 = clr & (h.dst == KS_KEY0), clr1 = clr & (h.dst == KS_KEY1);
         static_for<0, P>([&](auto I) {
             constexpr int i = decltype(I)::value;
             K0[i] = clr0 ? 0.0f : K0[i];
             K1[i] = clr1 ? 0.0f : K1[i];
         });
         /* one combined test, one merge point: a chain of early `continue`s made the compiler copy all 24
-           loop-carried registers at every exit. op.x0, op.x1 are multiples of 4: a lane is all in or all out. */
-        if (clr | !((y >= op.y0) & (y < op.y1) & (px0 >= op.x0) & (px0 < op.x1)))
+           loop-carried registers at every exit. x0, x1 are multiples of 4: a lane is all in or all out. */
+        if (clr | !((y >= h.y0) & (y < h.y1) & (px0 >= h.x0) & (px0 < h.x1)))
             continue;
-        const int  sx = px0 + op.unit_dx, sy = y + op.unit_dy;
-        const bool s16 = op.planes[0].bits == 16;
+        const int  sx = px0 + h.unit_dx, sy = y + h.unit_dy;
+        const bool s16 = h.bits0 == 16;
         f4         col[P];
-        if (op.fast_class == FC_PACKED) {
+        if (h.fast_class == FC_PACKED) {
             if (s16)
-                fetch_packed<16>(op, sx, sy, col);
+                fetch_packed<16>(h, sx, sy, col);
             else
-                fetch_packed<8>(op, sx, sy, col);
+                fetch_packed<8>(h, sx, sy, col);
         } else {
-            switch ((s16 ? 4 : 0) + op.csx + 2 * op.csy) {
-                case 0: fetch_planar<8, 0, 0>(op, sx, sy, col); break;
-                case 1: fetch_planar<8, 1, 0>(op, sx, sy, col); break;
-                case 2: fetch_planar<8, 0, 1>(op, sx, sy, col); break;
-                case 3: fetch_planar<8, 1, 1>(op, sx, sy, col); break;
-                case 4: fetch_planar<16, 0, 0>(op, sx, sy, col); break;
-                case 5: fetch_planar<16, 1, 0>(op, sx, sy, col); break;
-                case 6: fetch_planar<16, 0, 1>(op, sx, sy, col); break;
-                default: fetch_planar<16, 1, 1>(op, sx, sy, col); break;
+            switch ((s16 ? 4 : 0) + h.csx + 2 * h.csy) {
+                case 0: fetch_planar<8, 0, 0>(h, sx, sy, col); break;
+                case 1: fetch_planar<8, 1, 0>(h, sx, sy, col); break;
+                case 2: fetch_planar<8, 0, 1>(h, sx, sy, col); break;
+                case 3: fetch_planar<8, 1, 1>(h, sx, sy, col); break;
+                case 4: fetch_planar<16, 0, 0>(h, sx, sy, col); break;
+                case 5: fetch_planar<16, 1, 0>(h, sx, sy, col); break;
+                case 6: fetch_planar<16, 0, 1>(h, sx, sy, col); break;
+                default: fetch_planar<16, 1, 1>(h, sx, sy, col); break;
             }
         }
         /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
-        if (op.flags & KF_CHROMA) {
+        if (h.flags & KF_CHROMA) {
             static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key(col[decltype(I)::value], op); });
         }
-        if (op.flags & KF_LEVELS) {
+        if (h.flags & KF_LEVELS) {
             static_for<0, P>([&](auto I) {
                 constexpr int i = decltype(I)::value;
                 col[i].x = levels1(col[i].x, op), col[i].y = levels1(col[i].y, op), col[i].z = levels1(col[i].z, op);
             });
         }
-        if (op.flags & KF_CSB) {
+        if (h.flags & KF_CSB) {
             static_for<0, P>([&](auto I) { csb(col[decltype(I)::value], op); });
         }
-        const bool simple =
-            op.local_key == KS_NONE && op.layer_key == KS_NONE && !(op.flags & (KF_INVERT | KF_ADDITIVE));
-        if (op.dst >= KS_KEY0) {
+        const bool simple = h.local_key == KS_NONE && h.layer_key == KS_NONE && !(h.flags & (KF_INVERT | KF_ADDITIVE));
+        if (h.dst >= KS_KEY0) {
             if (simple)
-                blend_key4<BITS, true>(op, col, K0, K1);
+                blend_key4<BITS, true>(h, col, K0, K1);
             else
-                blend_key4<BITS, false>(op, col, K0, K1);
+                blend_key4<BITS, false>(h, col, K0, K1);
         } else {
             if (simple)
-                blend_rgba4<BITS, true>(op, col, S, K0, K1);
+                blend_rgba4<BITS, true>(h, col, S, K0, K1);
             else
-                blend_rgba4<BITS, false>(op, col, S, K0, K1);
+                blend_rgba4<BITS, false>(h, col, S, K0, K1);
         }
     }
 
