@@ -13,7 +13,12 @@
  *  - the store after EVERY draw rounds to UNORM8/16 (round-to-nearest-even of x*(2^n-1)), emulated in
  *    registers between ops, because every reference draw lands in an RGBA8 texture;
  *  - 8-bit textures are filtered with 8-bit weights and rounded integer lerps, 16-bit ones in fp32;
- *  - coverage uses 24.8 fixed-point edge functions with the top-left rule (exact, in double).
+ *  - coverage uses 24.8 fixed-point edge functions with the top-left rule (exact, in double);
+ *  - this file is compiled with -ffp-contract=off (csrc/Makefile): llvmpipe's JIT never fuses a multiply with
+ *    an add, and with contraction on about 2e-4 of 8-bit samples came out 1 LSB off, which a steep blend
+ *    (overlay, dodge) can double. The only fmas are explicit __builtin_fmaf calls whose single rounding is
+ *    proven equal to the reference's sequence (div_const, fdiv, quantize). With it every 8-bit golden scene
+ *    is bit-exact against the oracle; it costs ~5% of the kernel time.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -60,8 +65,10 @@ DEV float quantize(float x)
 #pragma clang fp contract(off)
     x             = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); /* NaN -> 0 like the clamp before a UNORM store */
     const float r = x * Q<BITS>::scale + Q<BITS>::magic; /* two roundings, never an fma (pragma above) */
-    const float t = r - Q<BITS>::magic;                  /* = k / 2^n exactly */
-    return t * Q<BITS>::dequant;                         /* = fl(k * fl(1/(2^n-1))) */
+    /* t = r - magic = k / 2^n exactly, result = fl(t * dequant) = fl(k * fl(1/(2^n-1))). One explicit fma does
+       both steps with the same single rounding: r*dequant - magic*dequant is (r - magic)*dequant exactly, and
+       magic*dequant is a power-of-two multiple of dequant, hence representable. */
+    return __builtin_fmaf(r, Q<BITS>::dequant, -Q<BITS>::magic * Q<BITS>::dequant);
 }
 template <int BITS>
 DEV uint32_t to_code(float q)
@@ -935,7 +942,8 @@ template <int BITS, bool SIMPLE>
 DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
 {
 #pragma clang fp contract(off)
-    const float opa = op.opacity;
+    float opa = op.opacity;
+    asm volatile("" : "+v"(opa)); /* VALU ops with an SGPR operand issue at ~2/3 rate (tests/ubench): one v_mov instead */
     if (SIMPLE) {
         static_for<0, 4>([&](auto I) {
             constexpr int i  = decltype(I)::value;
@@ -972,7 +980,8 @@ template <int BITS, bool SIMPLE>
 DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
 {
 #pragma clang fp contract(off)
-    const float opa  = op.opacity;
+    float opa = op.opacity;
+    asm volatile("" : "+v"(opa)); /* see blend_rgba4 */
     const bool  key1 = op.dst == KS_KEY1;
     const bool  lk = op.local_key != KS_NONE, yk = op.layer_key != KS_NONE;
     const bool  inv = op.flags & KF_INVERT, add = op.flags & KF_ADDITIVE;

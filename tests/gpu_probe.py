@@ -8,7 +8,7 @@ import server_amd as A
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import Channel, run_steps
 
-W, H = 3840, 2160
+W, H = int(os.environ.get("PROBE_W", "3840")), int(os.environ.get("PROBE_H", "2160"))
 NL = int(os.environ.get("PROBE_LAYERS", "8"))
 def stack(kind, bits):
     t = {"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
@@ -20,7 +20,7 @@ def stack(kind, bits):
     return S.scene("%s_%d" % (kind, bits), W, H, ops, bits=bits)
 
 which = os.environ.get("PROBE", "plain,key,chroma,levels,bgra").split(",")
-for bits in (16, 8):
+for bits in [int(b) for b in os.environ.get("PROBE_BITS", "16,8").split(",")]:
     for kind in which:
         sc = stack(kind, bits)
         ch = Channel(A, S, sc, 0, 1)

@@ -27,7 +27,11 @@ def mixer():
 
 
 def limits(sc):
-    return (1, 2e-3) if sc["bits"] == 8 else (2, 2e-2)
+    """(max |diff| in LSB, fraction of samples allowed to differ at all). BASELINE north star: +-1 LSB for 8-bit,
+    +-2 LSB for 16-bit output. 8-bit scenes must in fact equal the oracle bit for bit (the kernels are built
+    without FMA contraction and follow the shader's operation order); the llvmpipe goldens differ from the oracle
+    in ~4e-5 of the samples of the rotated scene, hence the non-zero fraction there."""
+    return (1, 1e-4) if sc["bits"] == 8 else (2, 5e-3)
 
 
 @pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
@@ -37,9 +41,13 @@ def test_hip_matches_oracle_and_golden(sc, mixer, goldens):
     gold = goldens[sc["name"]]
     mx, frac = limits(sc)
     st = S.diff_stats(got, ref)
-    assert st["max"] <= mx and st["gt0"] <= frac, ("vs oracle", st)
+    if sc["bits"] == 8:
+        assert st["max"] == 0, ("vs oracle: 8-bit output must be bit-exact", st)
+    else:
+        assert st["max"] <= mx and st["gt0"] <= frac, ("vs oracle", st)
     sg = S.diff_stats(got, gold)
-    assert sg["max"] <= mx and sg["gt0"] <= frac, ("vs llvmpipe golden", sg)
+    # 16-bit: the oracle itself is 1 LSB16 away from llvmpipe in ~0.5 % of samples (fp32 filter weights)
+    assert sg["max"] <= mx and sg["gt0"] <= (frac if sc["bits"] == 8 else 1e-2), ("vs llvmpipe golden", sg)
 
 
 def test_identity_is_bit_exact(mixer):
@@ -99,8 +107,8 @@ def test_two_channels_on_one_gpu_do_not_interfere(mixer):
             p1[i] = (a, b)
         ra, rb = S.run_oracle(s1, "cpu"), S.run_oracle(s2, "cpu")
         for a, b in p1:
-            assert S.diff_stats(mixer.get(a), ra)["max"] <= 1
-            assert S.diff_stats(other.get(b), rb)["max"] <= 1
+            assert np.array_equal(mixer.get(a), ra)
+            assert np.array_equal(other.get(b), rb)
     finally:
         other.close()
 
@@ -140,7 +148,7 @@ def test_fast_kernel_equals_general_kernel(mixer):
             assert st["gt1"] <= 1e-4 and st["gt0"] <= 2e-2, st
         ref = S.run_oracle(sc, "cpu")
         so = S.diff_stats(fast, ref)
-        assert (so["max"] <= 1 and so["gt0"] <= 2e-3) if bits == 8 else (so["gt2"] <= 1e-4), so
+        assert (so["max"] <= 1 and so["gt0"] <= 1e-4) if bits == 8 else (so["gt2"] <= 1e-4), so
 
 
 FULL = [("config1", lambda: S.config1()), ("config2", lambda: S.config2()), ("config4", lambda: S.config4()),
@@ -155,9 +163,12 @@ def test_full_size_configs_match_oracle(name, make, mixer):
     got = S.run_product(sc, mixer=mixer, planes_cache=cache)
     ref = S.run_oracle(sc, "cpu", cache)
     st = S.diff_stats(got, ref)
-    if sc["bits"] == 8:
-        assert st["gt1"] <= 1e-5, st  # isolated blend-mode amplification samples only
-        assert st["max"] <= 4 and st["gt0"] <= 5e-3, st
+    if sc["bits"] == 8 and name != "config3_8bit":
+        assert st["max"] == 0, st  # bit-exact
+    elif sc["bits"] == 8:
+        # levels' pow() is v_log_f32 / v_exp_f32 here and libm powf in the oracle: a few samples per million land on
+        # the other side of a rounding boundary
+        assert st["max"] <= 1 and st["gt0"] <= 1e-4, st
     else:
         # 16-bit sources are filtered with fp32 weights: last-ulp coordinate differences move ~1 % of samples by
         # 1 LSB16, and the chroma key's hard thresholds (shader.frag:360-366 hue snap, :124-151) turn a few of those
