@@ -165,6 +165,7 @@ def host():
         Hh.cghost_future_get.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
         Hh.cghost_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         Hh.cghost_device_gc.argtypes = [C.c_int]
+        Hh.cghost_mixer_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         _host = Hh
     return _host
 
@@ -214,7 +215,8 @@ VFLIP_COORDS = [(0.0, 0.0, 0.0, 1.0), (1.0, 0.0, 1.0, 1.0), (1.0, 1.0, 1.0, 0.0)
 
 
 class Mixer:
-    """The C++ accelerator::hip::image_mixer, scripted. gpu=-2 builds a dry-run mixer (flatten only)."""
+    """The C++ accelerator::hip::image_mixer, scripted. gpu=-2 builds a dry-run mixer (flatten only); gpu=-100-g a
+    mixer on a device object of its own on GPU g (frames routed between it and other mixers are peer-copied)."""
 
     def __init__(self, channel_id=1, gpu=0):
         self.H = host()
@@ -223,6 +225,13 @@ class Mixer:
         self.h = h
         self._keep = []
         self.last_kernel_ms = 0.0
+
+    def device_info(self):
+        """info of the device object this mixer renders on, as a dict (device::info, device.cpp:335-416)"""
+        import json
+        buf = C.create_string_buffer(4096)
+        check_host(self.H.cghost_mixer_device_info(self.h, buf, 4096))
+        return json.loads(buf.value.decode())
 
     def close(self):
         if getattr(self, "h", None):

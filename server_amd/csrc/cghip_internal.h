@@ -43,6 +43,7 @@ struct cghip_device {
     cghip::pool device_pool; /* hipMalloc'd blocks: planes, frame outputs, op lists */
     cghip::pool pinned_pool; /* hipHostMalloc'd blocks */
     std::atomic<int64_t> planes_live{0}, tickets_live{0}, frames_rendered{0}, mixers{0};
+    std::atomic<int64_t> peer_copies{0}, peer_copy_bytes{0}; /* routed planes copied INTO this device */
 
     int  dev_alloc(size_t bytes, void** out);
     void dev_free(void* p, size_t bytes);

@@ -191,12 +191,14 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
                      "{\"gpu\":%d,\"name\":\"%s\",\"hbm_total_bytes\":%zu,\"hbm_free_bytes\":%zu,"
                      "\"device_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"pinned_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
-                     "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld}",
+                     "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld,"
+                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld}",
                      dev->gpu, dev->name.c_str(), total_b, free_b, dev->device_pool.count_total,
                      dev->device_pool.bytes_total, dev->device_pool.bytes_free, dev->pinned_pool.count_total,
                      dev->pinned_pool.bytes_total, dev->pinned_pool.bytes_free, (long long)dev->planes_live.load(),
                      (long long)dev->tickets_live.load(), (long long)dev->mixers.load(),
-                     (long long)dev->frames_rendered.load());
+                     (long long)dev->frames_rendered.load(), (long long)dev->peer_copies.load(),
+                     (long long)dev->peer_copy_bytes.load());
     if (n < 0 || (size_t)n >= capacity)
         return fail(CGHIP_ERR_INVALID, "info buffer too small");
     return CGHIP_OK;
@@ -349,6 +351,8 @@ int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_p
         cghip_plane_release(p);
         return fail_hip(e, "peer copy");
     }
+    dst_dev->peer_copies++;
+    dst_dev->peer_copy_bytes += (int64_t)src->bytes;
     *out = p;
     return CGHIP_OK;
 }

@@ -86,13 +86,19 @@ const char* cghost_last_error(void) { return g_err.c_str(); }
 
 int cghost_device_count(void) { return the_accelerator().device_count(); }
 
-/* gpu_index >= 0: that GPU; -1: accelerator's round-robin placement; -2: dry run (no device, flatten only) */
+/* gpu_index >= 0: that GPU; -1: accelerator's round-robin placement; -2: dry run (no device, flatten only);
+ * <= -100: a device object of its own on GPU (-100 - gpu_index), not shared with the accelerator's per-GPU one: its
+ * planes and pools are foreign to every other mixer, which is how a route between two GPUs looks to the host code
+ * (lets the routed path be exercised on a one-GPU box). */
 int cghost_mixer_create(int channel_id, int gpu_index, void** out)
 {
     return guarded([&] {
         auto hm = std::make_unique<host_mixer>();
         if (gpu_index == -2) {
             hm->mixer = std::make_unique<hip::image_mixer>(nullptr, channel_id);
+        } else if (gpu_index <= -100) {
+            hm->dev   = std::make_shared<hip::device>(-100 - gpu_index);
+            hm->mixer = std::make_unique<hip::image_mixer>(hm->dev, channel_id);
         } else if (gpu_index == -1) {
             hm->mixer = the_accelerator().create_image_mixer(channel_id);
         } else {
@@ -280,6 +286,20 @@ int cghost_device_info(int gpu_index, char* json, size_t capacity)
 {
     return guarded([&] {
         auto s = the_accelerator().get_device(gpu_index)->info();
+        if (s.size() + 1 > capacity)
+            throw invalid_argument("info buffer too small");
+        std::memcpy(json, s.c_str(), s.size() + 1);
+    });
+}
+
+/* info of the device object a mixer renders on (the accelerator's shared one or a private one) */
+int cghost_mixer_device_info(void* h, char* json, size_t capacity)
+{
+    return guarded([&] {
+        auto* hm = static_cast<host_mixer*>(h);
+        if (!hm || !hm->dev)
+            throw invalid_argument("mixer has no device");
+        auto s = hm->dev->info();
         if (s.size() + 1 > capacity)
             throw invalid_argument("info buffer too small");
         std::memcpy(json, s.c_str(), s.size() + 1);

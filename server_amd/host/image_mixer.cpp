@@ -110,12 +110,40 @@ plane_ptr own(cghip_plane* p)
 }
 
 /* what const_frame::opaque() carries for frames created by this mixer: uploaded planes + the pinned
- * arrays they are being copied from (kept until the frame that uses them has rendered) */
+ * arrays they are being copied from (kept until the frame that uses them has rendered).
+ *
+ * Routes (core/producer/route/route_producer.cpp:40-126): a frame made on one channel is visited by
+ * mixers of other channels, possibly on another GPU. `home` names the device the planes live on; a mixer on another
+ * device gets a device-to-device copy over xGMI (cghip_plane_peer_copy_async), and the copy is cached HERE, per
+ * destination device, so that N routes of one frame onto a GPU (or N ticks showing the same still) copy it once. The
+ * cache dies with the frame. */
 struct uploaded
 {
     std::vector<plane_ptr>                 planes;
     std::vector<array<const std::uint8_t>> sources;
     int                                    magic = 0x48495031; /* "HIP1": recognise our own opaque */
+    cghip_device*                          home  = nullptr;
+    std::vector<plane_ptr>                 origin; /* routed copy: the source planes, alive until the copy has run */
+    std::mutex                                                        route_mu;
+    std::vector<std::pair<cghip_device*, std::shared_ptr<uploaded>>> routed;
+
+    std::shared_ptr<uploaded> on_device(cghip_device* dst)
+    {
+        std::lock_guard<std::mutex> g(route_mu);
+        for (auto& r : routed)
+            if (r.first == dst)
+                return r.second;
+        auto copy  = std::make_shared<uploaded>();
+        copy->home = dst;
+        for (auto& pl : planes) {
+            cghip_plane* out = nullptr;
+            check(cghip_plane_peer_copy_async(dst, pl.get(), &out), "cghip_plane_peer_copy_async");
+            copy->planes.push_back(own(out));
+        }
+        copy->origin = planes;
+        routed.emplace_back(dst, copy);
+        return copy;
+    }
 };
 
 struct item /* image_mixer.cpp:54-60 */
@@ -392,7 +420,8 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
         /* pointer-form any_cast: tolerate empty / foreign opaque (SURVEY 8b ownership) */
         auto up = std::static_pointer_cast<uploaded>(frame.opaque());
         if (up && up->magic == 0x48495031 && up->planes.size() == it.pix_desc.planes.size()) {
-            it.textures = up;
+            /* a routed frame whose planes live on another device is copied over once per destination device */
+            it.textures = (dev_ && up->home && up->home != dev_->handle()) ? up->on_device(dev_->handle()) : up;
         } else {
             it.textures = upload(it.pix_desc, [&](int n) { return frame.image_data(static_cast<std::size_t>(n)); });
         }
@@ -408,7 +437,8 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
     template <class F>
     std::shared_ptr<uploaded> upload(const core::pixel_format_desc& desc, F&& source_of)
     {
-        auto up = std::make_shared<uploaded>();
+        auto up  = std::make_shared<uploaded>();
+        up->home = dev_ ? dev_->handle() : nullptr;
         for (int n = 0; n < static_cast<int>(desc.planes.size()); ++n) {
             auto&        pl  = desc.planes[static_cast<std::size_t>(n)];
             auto         src = source_of(n);

@@ -193,3 +193,49 @@ def test_full_size_properties(mixer):
     c = S.run_product(S.scene("c", W, H, base + [top]), mixer=mixer, planes_cache=cache)
     d = S.run_product(S.scene("d", W, H, [top]), mixer=mixer, planes_cache=cache)
     assert np.array_equal(c, d)
+
+
+def test_routed_frame_is_peer_copied_once_per_device(mixer):
+    """SURVEY 8f rank 1 (route_producer.cpp:40-126): a frame made by one channel's frame factory and visited by a mixer
+    on another device is copied device-to-device once per destination device, however many layers and ticks show it,
+    and composites exactly like a frame uploaded there. The second device is a private device object on GPU 0 (the
+    box has one GPU): to the host code and the C ABI that is a foreign device, the copy is hipMemcpyPeerAsync."""
+    import server_amd as A
+    W, H = 256, 128
+    other = A.Mixer(channel_id=7, gpu=-100)
+    try:
+        spec = S.ycbcr(W, H, "422", "video", 41)
+        planes = S._planes(spec, None)
+        sc = S.scene("route", W, H, [S.layer(S.bgra(W, H, "premul", 40)),
+                                     S.layer(spec, opacity=0.7, fill_scale=[0.5, 0.5]),
+                                     S.layer(spec, opacity=0.6, fill_translation=[0.25, 0.25])])
+        want = S.run_product(sc, mixer=other)
+        before = other.device_info()["peer_copies"]
+        routed = mixer.create_frame(spec["fmt"], planes)  # lives on `mixer`'s device
+        try:
+            for tick in range(2):
+                for op in sc["ops"]:
+                    if op[0] == "push":
+                        other.push(A.default_transform(**op[1]))
+                    elif op[0] == "visit" and op[1] is spec:
+                        other.visit_frame(routed)
+                    elif op[0] == "visit":
+                        other.visit(op[1]["fmt"], S._planes(op[1], None), op[1].get("coords"))
+                    else:
+                        other.pop()
+                got = other.get(other.render_async(W, H))
+                assert np.array_equal(got, want)
+            info = other.device_info()
+            assert info["peer_copies"] - before == len(planes), info  # 2 layers x 2 ticks, one copy per plane
+            assert info["peer_copy_bytes"] >= sum(p.nbytes for p in planes)
+            # the same frame visited on its home device is shared, not copied
+            home_before = mixer.device_info()["peer_copies"]
+            mixer.push(A.default_transform(layer_depth=1))
+            mixer.visit_frame(routed)
+            mixer.pop()
+            mixer.get(mixer.render_async(W, H))
+            assert mixer.device_info()["peer_copies"] == home_before
+        finally:
+            mixer.destroy_frame(routed)
+    finally:
+        other.close()
