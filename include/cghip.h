@@ -137,6 +137,10 @@ int cghip_plane_desc(const cghip_plane* plane, int* width, int* height, int* cha
 /* route producers (core/producer/route/route_producer.cpp:40-126): a plane uploaded on another GPU is
  * copied device-to-device over xGMI; the reference shares one GL context instead (accelerator.cpp:27-34). */
 int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_plane** out);
+/* A second plane over the SAME device bytes with another shape (width*height*channels must match). The uyvy
+ * pixel format is two views of one buffer, RG8 w x h and RGBA8 (w/2) x h; the reference uploads those bytes
+ * twice (modules/ffmpeg/util/av_util.cpp:163-171, TODO at :45). The view retains its parent. */
+int cghip_plane_view(cghip_plane* src, int width, int height, int channels, cghip_plane** out);
 
 /* ---- mixer: replaces image_renderer::operator() + image_kernel::draw
  *      (ogl/image/image_mixer.cpp:86-226, ogl/image/image_kernel.cpp:134-420) ------------------- */

@@ -44,6 +44,7 @@ struct cghip_device {
     cghip::pool pinned_pool; /* hipHostMalloc'd blocks */
     std::atomic<int64_t> planes_live{0}, tickets_live{0}, frames_rendered{0}, mixers{0};
     std::atomic<int64_t> peer_copies{0}, peer_copy_bytes{0}; /* routed planes copied INTO this device */
+    std::atomic<int64_t> uploads{0}, upload_bytes{0};        /* host-to-device plane uploads */
 
     int  dev_alloc(size_t bytes, void** out);
     void dev_free(void* p, size_t bytes);
@@ -65,6 +66,7 @@ struct cghip_plane {
     hipEvent_t       ready    = nullptr; /* recorded after the upload / peer copy */
     std::atomic<int> refs{1};
     bool             stub = false; /* planner tests: no device memory behind it */
+    cghip_plane*     parent = nullptr; /* cghip_plane_view: dptr and ready belong to the parent, which is retained */
 };
 
 struct cghip_mixer {

@@ -192,13 +192,14 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
                      "\"device_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"pinned_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld,"
-                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld}",
+                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld,\"uploads\":%lld,\"upload_bytes\":%lld}",
                      dev->gpu, dev->name.c_str(), total_b, free_b, dev->device_pool.count_total,
                      dev->device_pool.bytes_total, dev->device_pool.bytes_free, dev->pinned_pool.count_total,
                      dev->pinned_pool.bytes_total, dev->pinned_pool.bytes_free, (long long)dev->planes_live.load(),
                      (long long)dev->tickets_live.load(), (long long)dev->mixers.load(),
                      (long long)dev->frames_rendered.load(), (long long)dev->peer_copies.load(),
-                     (long long)dev->peer_copy_bytes.load());
+                     (long long)dev->peer_copy_bytes.load(), (long long)dev->uploads.load(),
+                     (long long)dev->upload_bytes.load());
     if (n < 0 || (size_t)n >= capacity)
         return fail(CGHIP_ERR_INVALID, "info buffer too small");
     return CGHIP_OK;
@@ -283,6 +284,8 @@ int cghip_plane_upload_async(cghip_device* dev, const void* src, int width, int 
         cghip_plane_release(p);
         return fail_hip(e, "plane upload");
     }
+    dev->uploads++;
+    dev->upload_bytes += (int64_t)p->bytes;
     *out = p;
     return CGHIP_OK;
 }
@@ -301,6 +304,12 @@ int cghip_plane_release(cghip_plane* plane)
         return CGHIP_OK;
     if (--plane->refs > 0)
         return CGHIP_OK;
+    if (plane->parent) { /* a view owns nothing but its reference to the parent */
+        cghip_plane* parent = plane->parent;
+        plane->dev->planes_live--;
+        delete plane;
+        return cghip_plane_release(parent);
+    }
     if (!plane->stub) {
         /* the block goes back to the pool; whoever takes it next writes on a stream that is ordered after
            every reader through the ready event chain, or after the ticket that retained the plane */
@@ -353,6 +362,24 @@ int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_p
     }
     dst_dev->peer_copies++;
     dst_dev->peer_copy_bytes += (int64_t)src->bytes;
+    *out = p;
+    return CGHIP_OK;
+}
+
+int cghip_plane_view(cghip_plane* src, int width, int height, int channels, cghip_plane** out)
+{
+    if (!src || !out || src->stub)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    if (width <= 0 || height <= 0 || channels < 1 || channels > 4 ||
+        (size_t)width * height * channels * (src->bits / 8) != src->bytes)
+        return fail(CGHIP_ERR_INVALID, "a view must cover exactly the parent's bytes");
+    cghip_plane* root = src->parent ? src->parent : src;
+    cghip_plane* p    = new cghip_plane();
+    p->dev = src->dev, p->dptr = root->dptr, p->bytes = root->bytes, p->ready = root->ready;
+    p->width = width, p->height = height, p->channels = channels, p->bits = src->bits;
+    p->parent = root;
+    cghip_plane_retain(root);
+    p->dev->planes_live++;
     *out = p;
     return CGHIP_OK;
 }

@@ -443,6 +443,15 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
             auto&        pl  = desc.planes[static_cast<std::size_t>(n)];
             auto         src = source_of(n);
             cghip_plane* p   = nullptr;
+            /* uyvy is two views of the same bytes (RG8 w x h, RGBA8 w/2 x h: av_util.cpp:163-171); the reference
+               uploads them twice (TODO at av_util.cpp:45). Upload once, alias the second. */
+            if (dev_ && n == 1 && desc.format == core::pixel_format::uyvy && desc.planes.size() == 2 &&
+                desc.planes[0].size == pl.size && desc.planes[0].bits == pl.bits) {
+                check(cghip_plane_view(up->planes[0].get(), pl.width, pl.height, pl.stride, &p), "cghip_plane_view");
+                up->planes.push_back(own(p));
+                up->sources.push_back(src);
+                continue;
+            }
             if (dev_)
                 check(cghip_plane_upload_async(dev_->handle(), src.data(), pl.width, pl.height, pl.stride, pl.bits, &p),
                       "cghip_plane_upload_async");

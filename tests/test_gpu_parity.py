@@ -239,3 +239,28 @@ def test_routed_frame_is_peer_copied_once_per_device(mixer):
             mixer.destroy_frame(routed)
     finally:
         other.close()
+
+
+def test_uyvy_bytes_are_uploaded_once(mixer):
+    """SURVEY 8f rank 2 (av_util.cpp:163-171, TODO at :45): uyvy binds the same bytes as RG8 w x h and RGBA8 w/2 x h;
+    the frame factory uploads them once and aliases the second plane. Output parity of uyvy is covered by the
+    fmt_uyvy_* golden scenes, which run through this path."""
+    W, H = 96, 64
+    spec = S.frame("uyvy", [(W, H, 2, "video", 77)])
+    planes = S.materialize(spec)
+    before = mixer.device_info()
+    f = mixer.create_frame("uyvy", planes)
+    try:
+        after = mixer.device_info()
+        assert after["uploads"] - before["uploads"] == 1
+        assert after["upload_bytes"] - before["upload_bytes"] == planes[0].nbytes
+        assert after["planes_live"] - before["planes_live"] == 2
+        sc = S.scene("uyvy1", W, H, [S.layer(spec, opacity=0.9)])
+        mixer.push(__import__("server_amd").default_transform(layer_depth=1, opacity=0.9))
+        mixer.visit_frame(f)
+        mixer.pop()
+        got = mixer.get(mixer.render_async(W, H))
+        assert np.array_equal(got, S.run_oracle(sc, "cpu"))
+    finally:
+        mixer.destroy_frame(f)
+    assert mixer.device_info()["planes_live"] == before["planes_live"]
