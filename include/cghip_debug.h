@@ -22,6 +22,9 @@ int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_
 /* Forces the general one-pixel-per-lane kernel even for frames the 4-pixels-per-lane kernel could run, so
  * tests can compare the two. */
 void cghip_debug_force_general_kernel(int on);
+/* Launches the 4-pixels-per-lane kernel with this much unused dynamic LDS, which caps the workgroups resident on a
+ * CU (160 KB each): occupancy experiments only (tests/gpu_occupancy.py). 0 = off. */
+void cghip_debug_pad_lds(int bytes);
 
 #ifdef __cplusplus
 }

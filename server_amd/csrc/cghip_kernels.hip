@@ -92,6 +92,15 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const GLOBAL_AS u32x2*    GU2;
 typedef const GLOBAL_AS u32x4*    GU4;
+typedef const GLOBAL_AS char*     GB;
+
+/* load through a wave-uniform base plus a 32-bit per-lane byte offset: the SGPR-base + VGPR-offset form of
+ * global_load, instead of a 64-bit multiply-add per lane and load */
+template <class T>
+DEV T load_at(GB base, uint32_t byte_off)
+{
+    return *(const GLOBAL_AS T*)(base + byte_off);
+}
 
 /* 8-bit texel as a packed word in MEMORY channel order (byte k = k-th sample of the texel) */
 DEV uint32_t load8(const KPlane& p, int x, int y)
@@ -603,6 +612,150 @@ DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
 
 DEV f4 sel4(bool c, f4 a, f4 b) { return f4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
 
+/* ---- straight-line bilinear bodies for the two common 8-bit layouts (KSampleClass) ---- */
+
+DEV int lerp8s(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); } /* == one byte of lerp8x4 */
+
+/* byte offsets of the four taps of a GL_LINEAR + CLAMP_TO_EDGE fetch at 24.8 fixed-point texel coordinates
+ * (already shifted by half a texel), and the two 8-bit weights */
+struct Taps {
+    uint32_t o00, o01, o10, o11;
+    int      wx, wy;
+};
+DEV Taps make_taps(int iu, int iv, int w, int h, uint32_t texel_bytes)
+{
+    int       x0 = iu >> 8, y0 = iv >> 8;
+    const int x1 = iclamp(x0 + 1, 0, w - 1), y1 = iclamp(y0 + 1, 0, h - 1);
+    x0           = iclamp(x0, 0, w - 1);
+    y0           = iclamp(y0, 0, h - 1);
+    const uint32_t r0 = (uint32_t)y0 * (uint32_t)w, r1 = (uint32_t)y1 * (uint32_t)w;
+    return Taps{(r0 + (uint32_t)x0) * texel_bytes, (r0 + (uint32_t)x1) * texel_bytes, (r1 + (uint32_t)x0) * texel_bytes,
+                (r1 + (uint32_t)x1) * texel_bytes, iu & 0xff, iv & 0xff};
+}
+/* 1-channel plane: the filtered code 0..255 (x first, then y, 8-bit intermediates: sample8_fixed for one byte;
+ * a zero weight leaves the first operand untouched, so no tap is conditional) */
+DEV float tap1(uint64_t ptr, const Taps t)
+{
+    const GB  b   = (GB)ptr;
+    const int a00 = load_at<uint8_t>(b, t.o00), a01 = load_at<uint8_t>(b, t.o01);
+    const int a10 = load_at<uint8_t>(b, t.o10), a11 = load_at<uint8_t>(b, t.o11);
+    return (float)lerp8s(lerp8s(a00, a01, t.wx), lerp8s(a10, a11, t.wx), t.wy);
+}
+/* 4-channel plane: the four filtered bytes, memory order */
+DEV uint32_t tap4(uint64_t ptr, const Taps t)
+{
+    const GB       b   = (GB)ptr;
+    const uint32_t a00 = load_at<uint32_t>(b, t.o00), a01 = load_at<uint32_t>(b, t.o01);
+    const uint32_t a10 = load_at<uint32_t>(b, t.o10), a11 = load_at<uint32_t>(b, t.o11);
+    return lerp8x4(lerp8x4(a00, a01, (uint32_t)t.wx), lerp8x4(a10, a11, (uint32_t)t.wx), (uint32_t)t.wy);
+}
+
+/* op fields of the general kernel, fetched in one scalar batch at the top of the op loop (see HotOp) */
+struct HotG {
+    int32_t  kind;
+    uint32_t flags;
+    int32_t  dst, src_surface, local_key, layer_key, pixel_format;
+    int32_t  x0, y0, x1, y1, unit_dx, unit_dy, sample_class;
+    uint64_t ptr0, ptr1, ptr2, ptr3;
+    int32_t  w0, h0, w1, h1;
+    float    fw0, fh0, fw1, fh1;
+};
+DEV HotG load_hot_g(const KOp& op)
+{
+    HotG h = {op.kind, op.flags, op.dst, op.src_surface, op.local_key, op.layer_key, op.pixel_format, op.x0, op.y0, op.x1,
+              op.y1, op.unit_dx, op.unit_dy, op.sample_class, (uint64_t)op.planes[0].ptr, (uint64_t)op.planes[1].ptr,
+              (uint64_t)op.planes[2].ptr, (uint64_t)op.planes[3].ptr, op.planes[0].w, op.planes[0].h, op.planes[1].w,
+              op.planes[1].h, op.planes[0].fw, op.planes[0].fh, op.planes[1].fw, op.planes[1].fh};
+    asm volatile(""
+                 : "+s"(h.kind), "+s"(h.flags), "+s"(h.dst), "+s"(h.src_surface), "+s"(h.local_key), "+s"(h.layer_key),
+                   "+s"(h.pixel_format), "+s"(h.x0), "+s"(h.y0), "+s"(h.x1), "+s"(h.y1), "+s"(h.unit_dx), "+s"(h.unit_dy),
+                   "+s"(h.sample_class), "+s"(h.ptr0), "+s"(h.ptr1), "+s"(h.ptr2), "+s"(h.ptr3), "+s"(h.w0), "+s"(h.h0),
+                   "+s"(h.w1), "+s"(h.h1), "+s"(h.fw0), "+s"(h.fh0), "+s"(h.fw1), "+s"(h.fh1));
+    return h;
+}
+
+/* SC_PLANAR8 / SC_PACKED8 source colour. Texel coordinates of a plane of size (fw, fh): normalised (s,t) give
+ * rint(s*fw*256) - 128 (sample_norm); at unit scale texel (px,py) of plane 0 gives rint((px+.5)*(fw/fw0)*256) - 128
+ * (sample_unit). */
+template <bool UNIT>
+DEV f4 source_color_class(const KOp& op, const HotG& h, float s, float t, int px, int py)
+{
+    auto coord = [&](float v, float size, float size0, int p) -> int {
+        if (UNIT)
+            return (int)__builtin_rintf(((float)p + 0.5f) * ((size / size0) * 256.0f)) - 128;
+        return (int)__builtin_rintf(v * size * 256.0f) - 128;
+    };
+    const Taps t0 = make_taps(coord(s, h.fw0, h.fw0, px), coord(t, h.fh0, h.fh0, py), h.w0, h.h0,
+                              h.sample_class == SC_PACKED8 ? 4u : 1u);
+    if (h.sample_class == SC_PACKED8) {
+        const int      pf  = h.pixel_format;
+        const uint32_t sel = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
+        const uint32_t m   = tap4(h.ptr0, t0);
+        const uint32_t u   = __builtin_amdgcn_perm(m, m, sel);
+        const float    sc  = 1.0f / 255.0f;
+        return f4{(float)(u & 0xff) * sc, (float)((u >> 8) & 0xff) * sc, (float)((u >> 16) & 0xff) * sc,
+                  (float)(u >> 24) * sc};
+    }
+    const float sc = 1.0f / 255.0f;
+    const Taps  t1 = make_taps(coord(s, h.fw1, h.fw0, px), coord(t, h.fh1, h.fh0, py), h.w1, h.h1, 1u);
+    const float Y = tap1(h.ptr0, t0) * sc, Cb = tap1(h.ptr1, t1) * sc, Cr = tap1(h.ptr2, t1) * sc;
+    float       A = 1.0f;
+    if (h.pixel_format == 6)
+        A = tap1(h.ptr3, t0) * sc;
+    return ycbcra_to_rgba(Y, Cb, Cr, A, h.flags & KF_IS_HD);
+}
+
+/* Source colour of a KOP_DRAW_PLANES at pixel (x,y); false when the pixel centre is outside the quad. */
+DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
+{
+    if (h.flags & KF_UNIT_SCALE) {
+        const int px = x + h.unit_dx, py = y + h.unit_dy;
+        color = h.sample_class != SC_GENERIC ? source_color_class<true>(op, h, 0.0f, 0.0f, px, py)
+                                             : source_color_unit(op, px, py);
+        return true;
+    }
+    const double dx = (double)x, dy = (double)y;
+    bool         in0 = true;
+    float        s, t;
+    if (!(h.flags & KF_RECT)) { /* which triangle covers the pixel centre, if any */
+        bool in1 = op.ntri > 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in0 = in0 && __builtin_fma(op.tri[0].e[k][0], dx, __builtin_fma(op.tri[0].e[k][1], dy, op.tri[0].e[k][2])) >= 0.0;
+            in1 = in1 && __builtin_fma(op.tri[1].e[k][0], dx, __builtin_fma(op.tri[1].e[k][1], dy, op.tri[1].e[k][2])) >= 0.0;
+        }
+        if (!in0 && !in1)
+            return false;
+    }
+    /* the varyings of both triangles are evaluated and the results selected: selecting the 9 fp64 coefficients per
+       pixel costs more than the second evaluation */
+    {
+        const KTri& T0 = op.tri[0];
+        float s0 = (float)__builtin_fma(T0.a[0][1], dx, __builtin_fma(T0.a[0][2], dy, T0.a[0][0]));
+        float t0 = (float)__builtin_fma(T0.a[1][1], dx, __builtin_fma(T0.a[1][2], dy, T0.a[1][0]));
+        float q0 = 1.0f;
+        if (h.flags & KF_PROJECTIVE)
+            q0 = (float)__builtin_fma(T0.a[2][1], dx, __builtin_fma(T0.a[2][2], dy, T0.a[2][0]));
+        if (!(h.flags & KF_RECT)) {
+            const KTri& T1 = op.tri[1];
+            const float s1 = (float)__builtin_fma(T1.a[0][1], dx, __builtin_fma(T1.a[0][2], dy, T1.a[0][0]));
+            const float t1 = (float)__builtin_fma(T1.a[1][1], dx, __builtin_fma(T1.a[1][2], dy, T1.a[1][0]));
+            s0 = in0 ? s0 : s1, t0 = in0 ? t0 : t1;
+            if (h.flags & KF_PROJECTIVE) {
+                const float q1 = (float)__builtin_fma(T1.a[2][1], dx, __builtin_fma(T1.a[2][2], dy, T1.a[2][0]));
+                q0             = in0 ? q0 : q1;
+            }
+        }
+        s = s0, t = t0;
+        if (h.flags & KF_PROJECTIVE) {
+            s /= q0;
+            t /= q0;
+        }
+    }
+    color = h.sample_class != SC_GENERIC ? source_color_class<false>(op, h, s, t, 0, 0) : source_color_norm(op, s, t);
+    return true;
+}
+
 /* General compositor: one output pixel per lane (one wave = 64 consecutive pixels of a row, one
  * workgroup = 4 rows). FULL = false drops the two extra RGBA surfaces (layer / mix temporaries) from the
  * register file: the host picks it when the frame has only normal-blend, non-mix layers. Surfaces are
@@ -613,12 +766,10 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int y    = blockIdx.y * 4 + wave;
+    const int y    = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave); /* wave-uniform: keep it scalar */
     if (y >= H)
         return;
-    const int wave_x0 = blockIdx.x * 64;
-    const int wave_x1 = wave_x0 + 64;
-    const int x       = wave_x0 + lane;
+    const int x = blockIdx.x * 64 + lane;
 
     f4    s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     float k0 = 0.0f, k1 = 0.0f;
@@ -626,70 +777,45 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
     for (int n = 0; n < nops && row_live; ++n) {
-        const KOp& op = ops[n];
-        if (op.kind == KOP_CLEAR) {
-            if (FULL && op.dst == KS_RGBA1) s1 = f4{0, 0, 0, 0};
-            if (FULL && op.dst == KS_RGBA2) s2 = f4{0, 0, 0, 0};
-            if (op.dst == KS_KEY0) k0 = 0.0f;
-            if (op.dst == KS_KEY1) k1 = 0.0f;
-            continue;
+        const KOp& op  = ops[n];
+        const HotG h   = load_hot_g(op);
+        const bool clr = h.kind == KOP_CLEAR;
+        {
+            /* CLEAR as selects and ONE skip test: every early `continue` made the compiler copy all loop-carried
+               surface registers at that exit (see cghip_composite_fast) */
+            const bool c1 = clr & (h.dst == KS_RGBA1), c2 = clr & (h.dst == KS_RGBA2);
+            const bool c3 = clr & (h.dst == KS_KEY0), c4 = clr & (h.dst == KS_KEY1);
+            if (FULL) {
+                s1 = sel4(c1, f4{0, 0, 0, 0}, s1);
+                s2 = sel4(c2, f4{0, 0, 0, 0}, s2);
+            }
+            k0 = c3 ? 0.0f : k0;
+            k1 = c4 ? 0.0f : k1;
         }
-        /* wave-uniform cull against the op's touched box */
-        if (y < op.y0 || y >= op.y1 || wave_x1 <= op.x0 || wave_x0 >= op.x1)
-            continue;
-        if (x < op.x0 || x >= op.x1)
+        /* cull against the op's touched box, then against the quad itself */
+        bool live = !clr & (y >= h.y0) & (y < h.y1) & (x >= h.x0) & (x < h.x1);
+        f4   color = {0, 0, 0, 0};
+        if (live) {
+            if (h.kind == KOP_DRAW_SURFACE)
+                color = FULL ? sel4(h.src_surface == KS_RGBA2, s2, s1) : f4{0, 0, 0, 0};
+            else
+                live = source_color(op, h, x, y, color);
+        }
+        if (!live)
             continue;
 
-        f4 color;
-        if (op.kind == KOP_DRAW_SURFACE) {
-            color = FULL ? sel4(op.src_surface == KS_RGBA2, s2, s1) : f4{0, 0, 0, 0};
-        } else if (op.flags & KF_UNIT_SCALE) {
-            color = source_color_unit(op, x + op.unit_dx, y + op.unit_dy);
-        } else {
-            const double dx = (double)x, dy = (double)y;
-            int          t  = 0;
-            if (!(op.flags & KF_RECT)) { /* which triangle covers the pixel centre, if any */
-                bool in = true;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    in = in && __builtin_fma(op.tri[0].e[k][0], dx, __builtin_fma(op.tri[0].e[k][1], dy, op.tri[0].e[k][2])) >= 0.0;
-                if (!in) {
-                    in = op.ntri > 1;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        in = in && __builtin_fma(op.tri[1].e[k][0], dx, __builtin_fma(op.tri[1].e[k][1], dy, op.tri[1].e[k][2])) >= 0.0;
-                    if (!in)
-                        continue;
-                    t = 1;
-                }
-            }
-            double a[3][3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    a[j][k] = t ? op.tri[1].a[j][k] : op.tri[0].a[j][k];
-            float s  = (float)__builtin_fma(a[0][1], dx, __builtin_fma(a[0][2], dy, a[0][0]));
-            float tt = (float)__builtin_fma(a[1][1], dx, __builtin_fma(a[1][2], dy, a[1][0]));
-            if (op.flags & KF_PROJECTIVE) {
-                const float q = (float)__builtin_fma(a[2][1], dx, __builtin_fma(a[2][2], dy, a[2][0]));
-                s /= q;
-                tt /= q;
-            }
-            color = source_color_norm(op, s, tt);
-        }
-        const float lkey = op.local_key == KS_KEY1 ? k1 : k0;
-        const float ykey = op.layer_key == KS_KEY1 ? k1 : k0;
-        if (op.dst >= KS_KEY0) {
+        const float lkey = h.local_key == KS_KEY1 ? k1 : k0;
+        const float ykey = h.layer_key == KS_KEY1 ? k1 : k0;
+        if (h.dst >= KS_KEY0) {
             /* R8/R16 target (image_mixer.cpp:174-183): background.bgra of a 1-channel texture is
              * (0,0,r,1); only the red slot of the result is stored. */
-            const bool  one = op.dst == KS_KEY1;
+            const bool  one = h.dst == KS_KEY1;
             const f4    res = shade(op, color, lkey, ykey, f4{0.0f, 0.0f, one ? k1 : k0, 1.0f});
             const float q   = quantize<BITS>(res.z);
             k1              = one ? q : k1;
             k0              = one ? k0 : q;
         } else {
-            const bool d1 = FULL && op.dst == KS_RGBA1, d2 = FULL && op.dst == KS_RGBA2;
+            const bool d1 = FULL && h.dst == KS_RGBA1, d2 = FULL && h.dst == KS_RGBA2;
             f4         back = s0;
             if (FULL)
                 back = sel4(d1, s1, sel4(d2, s2, s0));
@@ -771,30 +897,33 @@ struct Row3 {
     uint32_t a, b, c;
 };
 
+/* Row address = wave-uniform base (the row index is scalar: every lane of a wave is on the same output row) plus a
+ * 32-bit per-lane byte offset, so the loads take the SGPR-base + VGPR-offset form instead of a 64-bit multiply-add
+ * per lane and load. */
 template <int SB, int HALF>
 DEV Row3 load_row(uint64_t ptr, int w, int r, int sx)
 {
     Row3 o = {0, 0, 0};
-    if (SB == 16) {
-        const G16 row = (G16)ptr + (size_t)r * (size_t)w;
-        if (!HALF) {
-            const u32x2 v = *(const GU2)(row + sx);
+    constexpr uint32_t B = SB / 8;
+    const GB row = (GB)ptr + (size_t)r * (size_t)w * B; /* scalar */
+    if (!HALF) {
+        if (SB == 16) {
+            const u32x2 v = load_at<u32x2>(row, (uint32_t)sx * B);
             o.a = v.x, o.b = v.y;
         } else {
-            const int k = sx >> 1;
-            o.a         = *(const G32)(row + k);
-            o.b         = row[imax(k - 1, 0)];
-            o.c         = row[imin(k + 2, w - 1)];
+            o.a = load_at<uint32_t>(row, (uint32_t)sx);
         }
     } else {
-        const G8 row = (G8)ptr + (size_t)r * (size_t)w;
-        if (!HALF) {
-            o.a = *(const G32)(row + sx);
+        const int      k  = sx >> 1;
+        const uint32_t kl = (uint32_t)imax(k - 1, 0), kr = (uint32_t)imin(k + 2, w - 1);
+        if (SB == 16) {
+            o.a = load_at<uint32_t>(row, (uint32_t)k * B);
+            o.b = load_at<uint16_t>(row, kl * B);
+            o.c = load_at<uint16_t>(row, kr * B);
         } else {
-            const int k = sx >> 1;
-            o.a         = *(const G16)(row + k);
-            o.b         = row[imax(k - 1, 0)];
-            o.c         = row[imin(k + 2, w - 1)];
+            o.a = load_at<uint16_t>(row, (uint32_t)k);
+            o.b = load_at<uint8_t>(row, kl);
+            o.c = load_at<uint8_t>(row, kr);
         }
     }
     return o;
@@ -910,7 +1039,7 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
     const int pf = op.pixel_format;
     if (SB == 8) {
         const uint32_t sel  = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
-        const u32x4    v    = *(const GU4)((G32)op.ptr0 + (size_t)sy * (size_t)op.w0 + sx);
+        const u32x4    v    = load_at<u32x4>((GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 4, (uint32_t)sx * 4u);
         const uint32_t m[4] = {v.x, v.y, v.z, v.w};
         const float    sc   = 1.0f / 255.0f;
 #pragma unroll
@@ -922,8 +1051,8 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
     } else {
         const uint32_t slo = pf == 1 ? 0x03020100u : pf == 2 ? 0x03020504u : pf == 3 ? 0x05040706u : 0x01000302u;
         const uint32_t shi = pf == 1 ? 0x07060504u : pf == 2 ? 0x07060100u : pf == 3 ? 0x01000302u : 0x05040706u;
-        const GU4      src = (const GU4)((GU2)op.ptr0 + (size_t)sy * (size_t)op.w0 + sx);
-        const u32x4    v = src[0], w = src[1];
+        const GB       row = (GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 8;
+        const u32x4    v = load_at<u32x4>(row, (uint32_t)sx * 8u), w = load_at<u32x4>(row, (uint32_t)sx * 8u + 16u);
         const uint32_t m[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
         const float    sc   = 1.0f / 65535.0f;
 #pragma unroll
@@ -1015,7 +1144,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     constexpr int P    = 4;
     const int     lane = threadIdx.x & 63;
     const int     wave = threadIdx.x >> 6;
-    const int     y    = blockIdx.y * 4 + wave;
+    const int     y    = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave); /* wave-uniform: keep it scalar */
     if (y >= H)
         return;
     const int px0 = blockIdx.x * 64 * P + lane * P;
@@ -1131,7 +1260,10 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
 /* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
 
 static int g_force_general = 0;
+static int g_pad_lds       = 0;
 extern "C" void cghip_debug_force_general_kernel(int on) { g_force_general = on; }
+/* occupancy experiments: dynamic LDS nobody touches, to cap the workgroups resident on a CU (160 KB per CU) */
+extern "C" void cghip_debug_pad_lds(int bytes) { g_pad_lds = bytes; }
 
 extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
                                              int field_mode, int full, int fast, hipStream_t stream)
@@ -1140,9 +1272,9 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
     if (fast && !full && !g_force_general) {
         dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4));
         if (bits == 8)
-            hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
         else
-            hipLaunchKernelGGL((cghip_composite_fast<16>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<16>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
         return hipGetLastError();
     }
     dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4));

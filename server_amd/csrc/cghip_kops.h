@@ -38,6 +38,14 @@ enum KFastClass : int32_t {
     FC_PLANAR = 2  /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
 };
 
+/* How cghip_composite samples a KOP_DRAW_PLANES source (host classification, cghip_plan.cpp). The two common
+ * layouts have straight-line bilinear bodies; everything else takes the generic per-format path. */
+enum KSampleClass : int32_t {
+    SC_GENERIC  = 0,
+    SC_PLANAR8  = 1, /* ycbcr / ycbcra, every plane 1 channel 8 bit, Cb and Cr of one size, alpha the size of Y */
+    SC_PACKED8  = 2  /* bgra / rgba / argb / abgr in one 4-channel 8-bit plane */
+};
+
 /* register-resident surfaces the kernel has names for */
 enum KSurf : int32_t {
     KS_NONE = -1,
@@ -88,7 +96,7 @@ struct KOp {
     /* fast-path classification (host, cghip_plan.cpp): 0 = general kernel only; FC_* otherwise */
     int32_t fast_class;
     float   ch_inv_spill, ch_inv_soft; /* 1/ch_spill, 1/(ch_softness - 1) */
-    int32_t pad_;
+    int32_t sample_class; /* KSampleClass */
     int32_t csx, csy; /* FC_PLANAR: chroma planes are 1/2 width (csx) and/or 1/2 height (csy) of plane 0 */
     KPlane  planes[4];
     KTri    tri[2];

@@ -229,6 +229,30 @@ static void classify_fast(KOp& op)
     }
 }
 
+/* which bilinear body of the general kernel fits the draw's source planes */
+static void classify_sampling(KOp& op)
+{
+    op.sample_class = SC_GENERIC;
+    if (op.kind != KOP_DRAW_PLANES)
+        return;
+    const int     pf = op.pixel_format;
+    const KPlane& p0 = op.planes[0];
+    if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4 && p0.bits == 8) {
+        op.sample_class = SC_PACKED8;
+        return;
+    }
+    if ((pf == 5 && op.nplanes == 3) || (pf == 6 && op.nplanes == 4)) {
+        for (int n = 0; n < op.nplanes; ++n)
+            if (op.planes[n].channels != 1 || op.planes[n].bits != 8)
+                return;
+        if (op.planes[1].w != op.planes[2].w || op.planes[1].h != op.planes[2].h)
+            return;
+        if (pf == 6 && (op.planes[3].w != p0.w || op.planes[3].h != p0.h))
+            return;
+        op.sample_class = SC_PLANAR8;
+    }
+}
+
 /* One reference draw -> one KOp. Returns 1 emitted, 0 skipped (reference early-out), <0 error. */
 static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
 {
@@ -499,6 +523,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
         if (surfaces[d.target].channels == 1 && d.source_surface >= 0)
             return fail(CGHIP_ERR_INVALID, "surface-to-key draws do not exist in the reference renderer");
         classify_fast(op); /* dst is known now */
+        classify_sampling(op);
         out->ops.push_back(op);
         if (d.source_surface < 0)
             for (int n = 0; n < d.nplanes; ++n)

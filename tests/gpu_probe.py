@@ -10,12 +10,18 @@ from bench import Channel, run_steps
 
 W, H = int(os.environ.get("PROBE_W", "3840")), int(os.environ.get("PROBE_H", "2160"))
 NL = int(os.environ.get("PROBE_LAYERS", "8"))
+SUB = os.environ.get("PROBE_SUB", "422")
 def stack(kind, bits):
     t = {"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
-         "levels": dict(opacity=0.7, **S.LEVELS), "bgra": dict(opacity=0.8)}[kind]
+         "levels": dict(opacity=0.7, **S.LEVELS), "bgra": dict(opacity=0.8),
+         # general-kernel paths: scaled (axis-aligned), rotated, perspective, unit-scale with a blend mode
+         "g_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]), "g_rot": dict(opacity=0.8, angle=0.05),
+         "g_pers": dict(opacity=0.8, pers_ul=[0.02, 0.01], pers_lr=[0.98, 0.99]),
+         "g_blend": dict(opacity=0.8, blend_mode="screen"), "g_bgra_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
+         "g_unit": dict(opacity=0.8, fill_translation=[1.0 / W, 0.0])}[kind]
     ops = []
     for i in range(NL):
-        spec = S.bgra(W, H, "premul", 500 + i, bits=bits) if kind == "bgra" else S.ycbcr(W, H, "422", "video", 500 + i, bits=bits)
+        spec = S.bgra(W, H, "premul", 500 + i, bits=bits) if "bgra" in kind else S.ycbcr(W, H, SUB, "video", 500 + i, bits=bits)
         ops.append(S.layer(spec, **t))
     return S.scene("%s_%d" % (kind, bits), W, H, ops, bits=bits)
 

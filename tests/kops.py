@@ -25,7 +25,7 @@ class KOp(C.Structure):
         ("ch_target_hue", C.c_float), ("ch_hue_width", C.c_float), ("ch_min_saturation", C.c_float),
         ("ch_min_brightness", C.c_float), ("ch_softness", C.c_float), ("ch_spill", C.c_float),
         ("ch_spill_saturation", C.c_float),
-        ("fast_class", C.c_int32), ("ch_inv_spill", C.c_float), ("ch_inv_soft", C.c_float), ("pad_", C.c_int32),
+        ("fast_class", C.c_int32), ("ch_inv_spill", C.c_float), ("ch_inv_soft", C.c_float), ("sample_class", C.c_int32),
         ("csx", C.c_int32), ("csy", C.c_int32),
         ("planes", KPlane * 4), ("tri", KTri * 2),
     ]
