@@ -135,7 +135,9 @@ int cghip_plane_retain(cghip_plane* plane);
 int cghip_plane_release(cghip_plane* plane);
 int cghip_plane_desc(const cghip_plane* plane, int* width, int* height, int* channels, int* bits, int* gpu_index);
 /* route producers (core/producer/route/route_producer.cpp:40-126): a plane uploaded on another GPU is
- * copied device-to-device over xGMI; the reference shares one GL context instead (accelerator.cpp:27-34). */
+ * copied device-to-device over xGMI; the reference shares one GL context instead (accelerator.cpp:27-34).
+ * The copy is enqueued, not waited for; the new plane retains `src` until it is released itself. Same device:
+ * `*out` is `src`, retained. */
 int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_plane** out);
 /* A second plane over the SAME device bytes with another shape (width*height*channels must match). The uyvy
  * pixel format is two views of one buffer, RG8 w x h and RGBA8 (w/2) x h; the reference uploads those bytes

@@ -67,6 +67,7 @@ struct cghip_plane {
     std::atomic<int> refs{1};
     bool             stub = false; /* planner tests: no device memory behind it */
     cghip_plane*     parent = nullptr; /* cghip_plane_view: dptr and ready belong to the parent, which is retained */
+    cghip_plane*     origin = nullptr; /* peer copy: the source plane, retained until this copy is released */
 };
 
 struct cghip_mixer {

@@ -310,6 +310,7 @@ int cghip_plane_release(cghip_plane* plane)
         delete plane;
         return cghip_plane_release(parent);
     }
+    cghip_plane* origin = plane->origin;
     if (!plane->stub) {
         /* the block goes back to the pool; whoever takes it next writes on a stream that is ordered after
            every reader through the ready event chain, or after the ticket that retained the plane */
@@ -321,7 +322,7 @@ int cghip_plane_release(cghip_plane* plane)
         plane->dev->planes_live--;
     }
     delete plane;
-    return CGHIP_OK;
+    return origin ? cghip_plane_release(origin) : CGHIP_OK;
 }
 
 int cghip_plane_desc(const cghip_plane* plane, int* width, int* height, int* channels, int* bits, int* gpu_index)
@@ -360,6 +361,9 @@ int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_p
         cghip_plane_release(p);
         return fail_hip(e, "peer copy");
     }
+    /* the copy is only enqueued: the source bytes must outlive it, so the copy holds its source plane */
+    cghip_plane_retain(src);
+    p->origin = src;
     dst_dev->peer_copies++;
     dst_dev->peer_copy_bytes += (int64_t)src->bytes;
     *out = p;

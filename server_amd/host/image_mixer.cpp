@@ -119,28 +119,32 @@ plane_ptr own(cghip_plane* p)
  * cache dies with the frame. */
 struct uploaded
 {
+    /* declared first = destroyed last: planes return their memory to their device's pools on release */
+    std::shared_ptr<device>                home_keep;   /* the device the planes live on */
+    std::shared_ptr<device>                origin_keep; /* routed copy: its planes retain the source planes */
     std::vector<plane_ptr>                 planes;
     std::vector<array<const std::uint8_t>> sources;
     int                                    magic = 0x48495031; /* "HIP1": recognise our own opaque */
     cghip_device*                          home  = nullptr;
-    std::vector<plane_ptr>                 origin; /* routed copy: the source planes, alive until the copy has run */
     std::mutex                                                        route_mu;
     std::vector<std::pair<cghip_device*, std::shared_ptr<uploaded>>> routed;
 
-    std::shared_ptr<uploaded> on_device(cghip_device* dst)
+    std::shared_ptr<uploaded> on_device(const std::shared_ptr<device>& dst_dev)
     {
+        cghip_device*               dst = dst_dev->handle();
         std::lock_guard<std::mutex> g(route_mu);
         for (auto& r : routed)
             if (r.first == dst)
                 return r.second;
-        auto copy  = std::make_shared<uploaded>();
-        copy->home = dst;
+        auto copy       = std::make_shared<uploaded>();
+        copy->home      = dst;
+        copy->home_keep   = dst_dev;
+        copy->origin_keep = home_keep;
         for (auto& pl : planes) {
-            cghip_plane* out = nullptr;
+            cghip_plane* out = nullptr; /* the copy retains its source plane (cghip.h) */
             check(cghip_plane_peer_copy_async(dst, pl.get(), &out), "cghip_plane_peer_copy_async");
             copy->planes.push_back(own(out));
         }
-        copy->origin = planes;
         routed.emplace_back(dst, copy);
         return copy;
     }
@@ -421,7 +425,7 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
         auto up = std::static_pointer_cast<uploaded>(frame.opaque());
         if (up && up->magic == 0x48495031 && up->planes.size() == it.pix_desc.planes.size()) {
             /* a routed frame whose planes live on another device is copied over once per destination device */
-            it.textures = (dev_ && up->home && up->home != dev_->handle()) ? up->on_device(dev_->handle()) : up;
+            it.textures = (dev_ && up->home && up->home != dev_->handle()) ? up->on_device(dev_) : up;
         } else {
             it.textures = upload(it.pix_desc, [&](int n) { return frame.image_data(static_cast<std::size_t>(n)); });
         }
@@ -438,7 +442,8 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
     std::shared_ptr<uploaded> upload(const core::pixel_format_desc& desc, F&& source_of)
     {
         auto up  = std::make_shared<uploaded>();
-        up->home = dev_ ? dev_->handle() : nullptr;
+        up->home      = dev_ ? dev_->handle() : nullptr;
+        up->home_keep = dev_;
         for (int n = 0; n < static_cast<int>(desc.planes.size()); ++n) {
             auto&        pl  = desc.planes[static_cast<std::size_t>(n)];
             auto         src = source_of(n);
@@ -505,7 +510,8 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
         check(cghip_mixer_render_async(mixer_, &fmt, surfaces.data(), static_cast<int>(surfaces.size()), draws.data(),
                                        static_cast<int>(draws.size()), readback_ ? CGHIP_RENDER_READBACK : 0u, &ticket),
               "cghip_mixer_render_async");
-        std::shared_ptr<cghip_ticket> owner(ticket, [](cghip_ticket* t) { cghip_ticket_release(t); });
+        /* consumers may hold the frame after the channel is gone (decklink / ndi queues): the buffer keeps its device */
+        std::shared_ptr<cghip_ticket> owner(ticket, [dev = dev_](cghip_ticket* t) { cghip_ticket_release(t); });
         auto                          self     = shared_from_this();
         auto                          keep     = std::make_shared<std::vector<layer>>(std::move(layers));
         const bool                    readback = readback_;
@@ -536,7 +542,7 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
             void*          ptr = nullptr;
             cghip_hostbuf* hb  = nullptr;
             check(cghip_host_alloc(dev_->handle(), static_cast<std::size_t>(plane.size), 1, &ptr, &hb), "cghip_host_alloc");
-            std::shared_ptr<void> storage(hb, [](void* h) { cghip_host_release(static_cast<cghip_hostbuf*>(h)); });
+            std::shared_ptr<void> storage(hb, [dev = dev_](void* h) { cghip_host_release(static_cast<cghip_hostbuf*>(h)); });
             image_data.emplace_back(static_cast<std::uint8_t*>(ptr), static_cast<std::size_t>(plane.size), storage);
         }
         std::weak_ptr<impl> weak_self = shared_from_this();

@@ -264,3 +264,26 @@ def test_uyvy_bytes_are_uploaded_once(mixer):
     finally:
         mixer.destroy_frame(f)
     assert mixer.device_info()["planes_live"] == before["planes_live"]
+
+
+def test_frames_outlive_their_mixer_and_device(mixer):
+    """Producers and consumers hold frames across channel teardown (decklink / ndi queues, SURVEY 8b ownership): a
+    frame made by a mixer whose device object is gone must still be visitable elsewhere and releasable."""
+    import server_amd as A
+    W, H = 128, 64
+    spec = S.bgra(W, H, "premul", 55)
+    planes = S.materialize(spec)
+    gone = A.Mixer(channel_id=9, gpu=-100)  # private device object: destroyed with the mixer unless a frame holds it
+    f = gone.create_frame(spec["fmt"], planes)
+    pending = gone.render_async(W, H)  # an empty frame in flight while the mixer goes away
+    gone.get(pending)
+    H_ = gone.H
+    gone.close()
+    try:
+        mixer.push(A.default_transform(layer_depth=1))
+        mixer.visit_frame(f)  # routed from the dead mixer's device: peer copy, then composite
+        mixer.pop()
+        got = mixer.get(mixer.render_async(W, H))
+        assert np.array_equal(got, planes[0])
+    finally:
+        H_.cghost_frame_destroy(f)
