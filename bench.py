@@ -142,13 +142,23 @@ def run_steps(ch, steps, in_flight=2):
 
 
 def end_to_end_fps(A, S, scene, gpu, steps):
-    """PCIe-inclusive: every step re-creates every source frame (pinned H2D) and reads the frame back (D2H)."""
+    """PCIe-inclusive: every step re-creates every source frame (copy into pinned memory + H2D) and reads the frame
+    back (D2H); two frames in flight like core::mixer (mixer.cpp:85-91)."""
     m = A.Mixer(channel_id=99, gpu=gpu)
     cache = {}
-    S.run_product(scene, mixer=m, planes_cache=cache)  # warm pools
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        S.run_product(scene, mixer=m, planes_cache=cache)
+    W, H, bits = scene["width"], scene["height"], scene["bits"]
+    prev = None
+    for i in range(steps + 3):
+        if i == 3:  # three pipelined frames first: the pinned and device pools grow to two frames in flight
+            m.get(prev)
+            prev = None
+            t0 = time.perf_counter()
+        S.feed_product(m, scene, cache)
+        cur = m.render_async(W, H, bits=bits, field_mode=scene.get("field_mode", 0))
+        if prev is not None:
+            m.get(prev)
+        prev = cur
+    m.get(prev)
     dt = time.perf_counter() - t0
     m.close()
     return steps / dt
@@ -211,7 +221,7 @@ def main():
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
-        e2e = end_to_end_fps(A, S, scene, gpu, 3)
+        e2e = end_to_end_fps(A, S, scene, gpu, 8)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(S, scene)

@@ -3,9 +3,17 @@
  * bench.py can drive push / visit / pop / render exactly as core::mixer does (core/mixer/mixer.cpp:62-92).
  * Not part of the drop-in boundary (that is include/cghip.h); this only makes the C++ host side scriptable.
  */
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "image_mixer.h"
 
@@ -25,6 +33,78 @@ struct host_mixer
     std::unique_ptr<hip::image_mixer> mixer;
     std::shared_ptr<hip::device>      dev;
 };
+
+/* Filling a pinned plane stands in for a decoder writing its output (modules/ffmpeg/util/av_util.cpp:40-80 copies
+ * row by row inside tbb::parallel_for). One thread moves ~10 GB/s, a 2160p 16-layer frame is 0.5 GB: the copy is
+ * split over a few persistent workers so that it keeps up with the PCIe upload that follows it. */
+class copy_pool
+{
+    std::vector<std::thread>          workers_;
+    std::mutex                        mu_;
+    std::condition_variable           cv_, done_cv_;
+    std::vector<std::function<void()>> tasks_;
+    int                               pending_ = 0;
+    bool                              stop_    = false;
+
+  public:
+    explicit copy_pool(int n)
+    {
+        for (int i = 0; i < n; ++i)
+            workers_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> task;
+                    {
+                        std::unique_lock<std::mutex> l(mu_);
+                        cv_.wait(l, [this] { return stop_ || !tasks_.empty(); });
+                        if (stop_ && tasks_.empty())
+                            return;
+                        task = std::move(tasks_.back());
+                        tasks_.pop_back();
+                    }
+                    task();
+                    std::lock_guard<std::mutex> l(mu_);
+                    if (--pending_ == 0)
+                        done_cv_.notify_all();
+                }
+            });
+    }
+    ~copy_pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_)
+            w.join();
+    }
+    void copy(void* dst, const void* src, std::size_t bytes)
+    {
+        const std::size_t chunk = std::size_t(2) << 20;
+        if (bytes <= 2 * chunk || workers_.empty()) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        std::unique_lock<std::mutex> l(mu_);
+        for (std::size_t off = 0; off < bytes; off += chunk) {
+            const std::size_t n = std::min(chunk, bytes - off);
+            tasks_.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, n); });
+            ++pending_;
+        }
+        cv_.notify_all();
+        done_cv_.wait(l, [this] { return pending_ == 0; });
+    }
+};
+
+copy_pool& the_copy_pool()
+{
+    static copy_pool p([] {
+        const char* e = std::getenv("CGHOST_COPY_THREADS");
+        int         n = e ? std::atoi(e) : 8;
+        return std::max(0, std::min(n, 32));
+    }());
+    return p;
+}
 
 void from_pod(const cghip_transform& o, core::image_transform& t)
 {
@@ -145,8 +225,8 @@ int cghost_mixer_visit(void* h, int pixel_format, int nplanes, const cghost_plan
         if (via_factory) {
             auto frame = mixer.create_frame(nullptr, desc);
             for (int n = 0; n < nplanes; ++n)
-                std::memcpy(frame.image_data(static_cast<std::size_t>(n)).data(), planes[n].data,
-                            static_cast<std::size_t>(desc.planes[static_cast<std::size_t>(n)].size));
+                the_copy_pool().copy(frame.image_data(static_cast<std::size_t>(n)).data(), planes[n].data,
+                                     static_cast<std::size_t>(desc.planes[static_cast<std::size_t>(n)].size));
             frame.geometry() = geometry;
             mixer.visit(core::const_frame(std::move(frame)));
         } else {
