@@ -985,28 +985,31 @@ DEV void convert_chroma(const Row3 t, const Row3 u, int sy, float o[4])
 
 /* source colours of four pixels from ycbcr / ycbcra planes (shader.frag:441-467,500-512) */
 template <int SB, int HX, int HY>
-DEV void fetch_planar(const HotOp& op, int sx, int sy, f4 col[4])
+DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
 {
+    /* red_only (wave-uniform): the draw lands in a key surface and has no colour adjustment, so only the red and
+       alpha slots are ever looked at (image_mixer.cpp:174-183): R = Y' + k*Cr' needs neither the Cb plane nor G, B */
     const int  r0    = (sy - 1) >> 1;
     const int  ra    = HY ? iclamp(r0, 0, op.h1 - 1) : sy;
     const int  rb    = HY ? iclamp(r0 + 1, 0, op.h1 - 1) : sy;
     const bool alpha = op.pixel_format == 6;
     /* all loads first: one HBM round trip per op, not one per plane */
     const Row3 y   = load_row<SB, 0>(op.ptr0, op.w0, sy, sx);
-    const Row3 cb0 = load_row<SB, HX>(op.ptr1, op.w1, ra, sx);
     const Row3 cr0 = load_row<SB, HX>(op.ptr2, op.w2, ra, sx);
-    Row3       cb1 = {0, 0, 0}, cr1 = {0, 0, 0}, al = {0, 0, 0};
-    if (HY) {
-        cb1 = load_row<SB, HX>(op.ptr1, op.w1, rb, sx);
+    Row3       cb0 = {0, 0, 0}, cb1 = {0, 0, 0}, cr1 = {0, 0, 0}, al = {0, 0, 0};
+    if (HY)
         cr1 = load_row<SB, HX>(op.ptr2, op.w2, rb, sx);
+    if (!red_only) {
+        cb0 = load_row<SB, HX>(op.ptr1, op.w1, ra, sx);
+        if (HY)
+            cb1 = load_row<SB, HX>(op.ptr1, op.w1, rb, sx);
     }
     if (alpha)
         al = load_row<SB, 0>(op.ptr3, op.w3, sy, sx);
 
     const float sc = SB == 8 ? 1.0f / 255.0f : 1.0f;
-    float       Y[4], Cb[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    float       Y[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     convert_row<SB, 0>(y, Y);
-    convert_chroma<SB, HX, HY>(cb0, cb1, sy, Cb);
     convert_chroma<SB, HX, HY>(cr0, cr1, sy, Cr);
     if (alpha) {
         convert_row<SB, 0>(al, Al);
@@ -1018,14 +1021,24 @@ DEV void fetch_planar(const HotOp& op, int sx, int sy, f4 col[4])
     const bool  hd  = op.flags & KF_IS_HD;
     const float krr = hd ? 1.793f : 1.596f, kgr = hd ? 0.534f : 0.813f, kgb = hd ? 0.213f : 0.391f,
                 kbb = hd ? 2.115f : 2.018f;
+    float yy[4], cr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float yy = 1.164f * ((SB == 8 ? Y[i] * sc : Y[i]) * 255.0f - 16.0f);
-        const float cb = Cb[i] * 255.0f - 128.0f, cr = Cr[i] * 255.0f - 128.0f;
-        col[i].z       = div_const((yy + krr * cr), 255.0f, 1.0f / 255.0f);
-        col[i].y       = div_const((yy - kgr * cr - kgb * cb), 255.0f, 1.0f / 255.0f);
-        col[i].x       = div_const((yy + kbb * cb), 255.0f, 1.0f / 255.0f);
-        col[i].w       = Al[i];
+        yy[i]    = 1.164f * ((SB == 8 ? Y[i] * sc : Y[i]) * 255.0f - 16.0f);
+        cr[i]    = Cr[i] * 255.0f - 128.0f;
+        col[i].z = div_const((yy[i] + krr * cr[i]), 255.0f, 1.0f / 255.0f);
+        col[i].w = Al[i];
+        col[i].x = col[i].y = 0.0f;
+    }
+    if (!red_only) {
+        float Cb[4];
+        convert_chroma<SB, HX, HY>(cb0, cb1, sy, Cb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float cb = Cb[i] * 255.0f - 128.0f;
+            col[i].y       = div_const((yy[i] - kgr * cr[i] - kgb * cb), 255.0f, 1.0f / 255.0f);
+            col[i].x       = div_const((yy[i] + kbb * cb), 255.0f, 1.0f / 255.0f);
+        }
     }
 }
 
@@ -1174,6 +1187,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
             continue;
         const int  sx = px0 + h.unit_dx, sy = y + h.unit_dy;
         const bool s16 = h.bits0 == 16;
+        const bool red_only = h.dst >= KS_KEY0 && !(h.flags & (KF_CHROMA | KF_LEVELS | KF_CSB));
         f4         col[P];
         if (h.fast_class == FC_PACKED) {
             if (s16)
@@ -1182,14 +1196,14 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
                 fetch_packed<8>(h, sx, sy, col);
         } else {
             switch ((s16 ? 4 : 0) + h.csx + 2 * h.csy) {
-                case 0: fetch_planar<8, 0, 0>(h, sx, sy, col); break;
-                case 1: fetch_planar<8, 1, 0>(h, sx, sy, col); break;
-                case 2: fetch_planar<8, 0, 1>(h, sx, sy, col); break;
-                case 3: fetch_planar<8, 1, 1>(h, sx, sy, col); break;
-                case 4: fetch_planar<16, 0, 0>(h, sx, sy, col); break;
-                case 5: fetch_planar<16, 1, 0>(h, sx, sy, col); break;
-                case 6: fetch_planar<16, 0, 1>(h, sx, sy, col); break;
-                default: fetch_planar<16, 1, 1>(h, sx, sy, col); break;
+                case 0: fetch_planar<8, 0, 0>(h, sx, sy, red_only, col); break;
+                case 1: fetch_planar<8, 1, 0>(h, sx, sy, red_only, col); break;
+                case 2: fetch_planar<8, 0, 1>(h, sx, sy, red_only, col); break;
+                case 3: fetch_planar<8, 1, 1>(h, sx, sy, red_only, col); break;
+                case 4: fetch_planar<16, 0, 0>(h, sx, sy, red_only, col); break;
+                case 5: fetch_planar<16, 1, 0>(h, sx, sy, red_only, col); break;
+                case 6: fetch_planar<16, 0, 1>(h, sx, sy, red_only, col); break;
+                default: fetch_planar<16, 1, 1>(h, sx, sy, red_only, col); break;
             }
         }
         /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
