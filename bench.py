@@ -235,6 +235,19 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload)
             except Exception:
                 traffic = None
+        # the vector-ALU side of the same launch: instruction count from the committed PMC pass,
+        # duration measured live; peak = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz
+        valu = None
+        pv = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
+        if os.path.exists(pv) and args.workload == "config3_16bit":
+            try:
+                n_valu = json.load(open(pv)).get("SQ_INSTS_VALU")
+                peak = 1024 * 2.4e9 / 2 / 1e9
+                ach = n_valu / (avg_kernel_ms * 1e-3) / 1e9
+                valu = {"wave_instr_per_launch": n_valu, "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
+                        "frac": ach / peak, "note": "kernel is VALU-issue bound; see DESIGN.md section 4"}
+            except Exception:
+                valu = None
         line = {
             "metric": "composited frames/s per GPU (2160p, 16 layers) + % of HBM roofline",
             "value": whole_job_value(world, args.steps, dt),
@@ -257,7 +270,7 @@ def main():
                          "kernel": "cghip_composite_fast<%d>" % scene["bits"] if args.workload in ("config3_16bit", "config3_8bit", "config1")
                          else "cghip_composite<%d>" % scene["bits"],
                          "avg_kernel_ms": avg_kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
             "cpu_baseline": cpu,
             "end_to_end_fps": e2e,
         }
