@@ -108,6 +108,11 @@ typedef struct cghip_draw {
 } cghip_draw;
 
 #define CGHIP_RENDER_READBACK 0x1u /* copy the frame to a pinned host buffer (device::copy_async(texture)) */
+/* With field_mode 1 / 2 and CGHIP_RENDER_READBACK: transfer only the rows of that field (half the D2H bytes). The
+ * host buffer keeps the full-frame layout; rows of the other field are unspecified. For consumers that weave two
+ * field renders themselves (modules/decklink/consumer/decklink_consumer.cpp:293-308,
+ * modules/newtek/consumer/newtek_ndi_consumer.cpp:135-140). */
+#define CGHIP_RENDER_FIELD_ROWS_ONLY 0x2u
 #define CGHIP_MAX_SURFACES 16
 
 /* ---- error reporting ------------------------------------------------------------------------- */

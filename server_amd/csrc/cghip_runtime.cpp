@@ -513,7 +513,17 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     T_HIP(hipEventRecord(t->ev_stop, t->stream));
     if (flags & CGHIP_RENDER_READBACK) {
         T_TRY(dev->pinned_alloc(t->out_bytes, &t->h_out));
-        T_HIP(hipMemcpyAsync(t->h_out, t->d_out, t->out_bytes, hipMemcpyDeviceToHost, t->stream));
+        const int fm = format->field_mode;
+        if ((flags & CGHIP_RENDER_FIELD_ROWS_ONLY) && (fm == 1 || fm == 2) && format->height > 1) {
+            /* only the rows the kernel drew: a strided copy of every second row */
+            const size_t row   = (size_t)format->width * 4 * (format->bits / 8);
+            const size_t first = fm == 1 ? 0 : 1;
+            const size_t rows  = ((size_t)format->height - first + 1) / 2;
+            T_HIP(hipMemcpy2DAsync((char*)t->h_out + first * row, 2 * row, (const char*)t->d_out + first * row, 2 * row,
+                                   row, rows, hipMemcpyDeviceToHost, t->stream));
+        } else {
+            T_HIP(hipMemcpyAsync(t->h_out, t->d_out, t->out_bytes, hipMemcpyDeviceToHost, t->stream));
+        }
     }
     T_HIP(hipEventRecord(t->ev_done, t->stream));
 #undef T_TRY

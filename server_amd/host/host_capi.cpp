@@ -299,6 +299,7 @@ int cghost_mixer_render(void* h, const cghip_format* f, void* out, size_t capaci
     return guarded([&] {
         auto& mixer = *static_cast<host_mixer*>(h)->mixer;
         mixer.set_readback(readback != 0);
+        mixer.set_field_rows_only(readback == 2);
         auto fut   = mixer(to_desc(f));
         auto frame = fut.get();
         if (out && readback) {
@@ -325,6 +326,7 @@ int cghost_mixer_render_async(void* h, const cghip_format* f, int readback, void
     return guarded([&] {
         auto& mixer = *static_cast<host_mixer*>(h)->mixer;
         mixer.set_readback(readback != 0);
+        mixer.set_field_rows_only(readback == 2); /* 2: only the rows of format.field_mode's field cross PCIe */
         *out = new pending_frame{mixer(to_desc(f)), &mixer, readback != 0};
     });
 }

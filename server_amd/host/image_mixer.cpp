@@ -362,6 +362,7 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
     std::vector<int>                   layer_path_; /* layer_stack_ (:236) as an index path: vectors may reallocate */
     float                              last_ms_  = 0.0f;
     bool                               readback_ = true;
+    bool                               field_rows_only_ = false;
 
     impl(const std::shared_ptr<device>& dev, int channel_id)
         : dev_(dev)
@@ -508,7 +509,10 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
                          format_desc.bits,  format_desc.field_mode};
         cghip_ticket* ticket = nullptr;
         check(cghip_mixer_render_async(mixer_, &fmt, surfaces.data(), static_cast<int>(surfaces.size()), draws.data(),
-                                       static_cast<int>(draws.size()), readback_ ? CGHIP_RENDER_READBACK : 0u, &ticket),
+                                       static_cast<int>(draws.size()),
+                                       (readback_ ? CGHIP_RENDER_READBACK : 0u) |
+                                           (field_rows_only_ ? CGHIP_RENDER_FIELD_ROWS_ONLY : 0u),
+                                       &ticket),
               "cghip_mixer_render_async");
         /* consumers may hold the frame after the channel is gone (decklink / ndi queues): the buffer keeps its device */
         std::shared_ptr<cghip_ticket> owner(ticket, [dev = dev_](cghip_ticket* t) { cghip_ticket_release(t); });
@@ -579,6 +583,7 @@ std::vector<draw_call> image_mixer::flatten(const core::video_format_desc& forma
 }
 float image_mixer::last_kernel_ms() const { return impl_->last_ms_; }
 void  image_mixer::set_readback(bool on) { impl_->readback_ = on; }
+void  image_mixer::set_field_rows_only(bool on) { impl_->field_rows_only_ = on; }
 
 /* ------------------------------------------------------------------ accelerator */
 

@@ -191,6 +191,9 @@ class image_mixer final
     std::vector<draw_call> flatten(const core::video_format_desc& format_desc, std::vector<cghip_surface>* surfaces);
     float                  last_kernel_ms() const;
     void                   set_readback(bool on); /* false: frames stay in HBM (kernel-only benchmarking) */
+    /* interlaced channels (format_desc.field_mode 1 / 2): read back only the rows of the rendered field; the
+       consumer weaves two such frames (decklink_consumer.cpp:293-308). Halves the D2H traffic. */
+    void                   set_field_rows_only(bool on);
 
   private:
     struct impl;

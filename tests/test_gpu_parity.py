@@ -287,3 +287,17 @@ def test_frames_outlive_their_mixer_and_device(mixer):
         assert np.array_equal(got, planes[0])
     finally:
         H_.cghost_frame_destroy(f)
+
+
+def test_field_rows_only_readback(mixer):
+    """SURVEY 8f rank 3: an interlaced channel reads back only the rows of the rendered field (half the D2H bytes);
+    those rows equal the full readback's, the other field's rows are unspecified."""
+    W, H = 128, 65  # odd height: the two fields have 33 and 32 rows
+    base = S.scene("f", W, H, [S.layer(S.bgra(W, H, "premul", 6), opacity=0.9)])
+    for mode, first in ((1, 0), (2, 1)):
+        sc = dict(base, field_mode=mode)
+        full = S.run_product(sc, mixer=mixer)
+        S.feed_product(mixer, sc)
+        got = mixer.get(mixer.render_async(W, H, field_mode=mode, readback=2))
+        assert np.array_equal(got[first::2], full[first::2])
+        assert np.array_equal(full[first::2], S.run_oracle(sc, "cpu")[first::2])
