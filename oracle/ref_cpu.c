@@ -152,6 +152,28 @@ static v4 sample(const cpu_tex* t, float s, float tt)
     return r;
 }
 
+/*
+ * texture(background, TexCoord2.st): the draw reads the target it is writing (glTextureBarrier, image_kernel.cpp:
+ * 405-411), at the fragment's own pixel centre. On the 8-bit fixed-point path the weights quantise to exactly 0, so
+ * this is the pixel's own texel. On the float path (16-bit targets) the interpolated coordinate is a few ulp off the
+ * centre, the weight of a NEIGHBOUR is ~1e-6 instead of 0, and that neighbour may already hold this draw's output:
+ * which neighbours do depends on the rasteriser's traversal order (llvmpipe: 4x4 blocks inside 64x64 tiles; a
+ * scanline loop like cpu_draw: always the left one), i.e. it is the undefined part of reading one's own target.
+ * The restatement takes the defined part: the pixel's own texel. (Found by tests/test_fuzz.py: with the bilinear
+ * fetch this file was 1 LSB16 off llvmpipe AND the HIP mixer on ~0.4 % of samples of a plain stretched layer.)
+ */
+static v4 sample_own_pixel(const cpu_tex* t, float s, float tt)
+{
+    if (t->bits == 8)
+        return sample(t, s, tt);
+    int x = clampi((int)floorf(s * (float)t->w), 0, t->w - 1);
+    int y = clampi((int)floorf(tt * (float)t->h), 0, t->h - 1);
+    int c[4];
+    texel_int(t, x, y, c);
+    const float sc = 1.0f / 65535.0f;
+    return (v4){(float)c[0] * sc, (float)c[1] * sc, (float)c[2] * sc, (float)c[3] * sc};
+}
+
 /* ------------------------------------------------------------------ GLSL helpers */
 
 static float fminf_(float a, float b) { return a < b ? a : b; }
@@ -527,7 +549,7 @@ static v4 fragment(const ref_draw* d, v4 tc, float s2, float t2)
     if (d->invert)
         color = (v4){1.0f - color.x, 1.0f - color.y, 1.0f - color.z, 1.0f - color.w};
     if (d->blend_mode >= 0) { /* blend() :424-434 */
-        v4 bs   = sample((const cpu_tex*)d->background, s2, t2);
+        v4 bs   = sample_own_pixel((const cpu_tex*)d->background, s2, t2);
         v4 back = {bs.z, bs.y, bs.x, bs.w}; /* .bgra */
         v4 fore = color;
         if (d->blend_mode != 0) {

@@ -253,11 +253,16 @@ DEV float div_const(float x, float c, float rc)
     return __builtin_fmaf(r, rc, q);
 }
 
-/* a / b with one Newton step on v_rcp_f32: correctly rounded for the finite, non-zero denominators this shader
- * produces (alpha + 1e-7, 6d + 1e-10, ...), in ~5 issue slots instead of the ~14 of the IEEE divide sequence. */
+/* a / b, correctly rounded, for the finite, normal-range denominators this shader produces (alpha + 1e-7,
+ * 6d + 1e-10, ...): v_rcp_f32 (1 ulp) is first refined to the correctly rounded reciprocal, then the quotient gets
+ * one residual correction (Markstein). 6 issue slots + the rcp instead of the ~14 of the IEEE divide sequence, whose
+ * extra work is scaling for denormal / huge operands that cannot occur here. A single Newton step on the raw rcp
+ * was not enough: a random-scene test found a quotient one ulp off (1 LSB on a chroma-keyed gray pixel). */
 DEV float fdiv(float a, float b)
 {
-    const float rb = __builtin_amdgcn_rcpf(b);
+    float       rb = __builtin_amdgcn_rcpf(b);
+    const float e  = __builtin_fmaf(-b, rb, 1.0f);
+    rb             = __builtin_fmaf(e, rb, rb);
     const float q  = a * rb;
     const float r  = __builtin_fmaf(-q, b, a);
     return __builtin_fmaf(r, rb, q);
@@ -317,13 +322,13 @@ DEV f4 chroma_key(f4 c, const KOp& op)
     f3          sp       = hsv;
     float       diff     = hsv.x - op.ch_target_hue;
     diff                 = diff < -0.5f ? diff + 1.0f : (diff > 0.5f ? diff - 1.0f : diff);
-    const float dist     = __builtin_fabsf(diff) * op.ch_inv_spill;
+    const float dist     = div_const(__builtin_fabsf(diff), op.ch_spill, op.ch_inv_spill);
     if (dist < 1.0f) {
         sp.x = diff < 0.0f ? op.ch_target_hue - op.ch_spill : op.ch_target_hue + op.ch_spill;
         sp.y *= __builtin_fminf(1.0f, dist + op.ch_spill_saturation);
     }
     const f3    rgb   = hsv2rgb(sp);
-    const float t     = clamp01((dd - 1.0f) * op.ch_inv_soft); /* smoothstep(1, softness, d) */
+    const float t     = clamp01(div_const(dd - 1.0f, op.ch_soft_range, op.ch_inv_soft)); /* smoothstep(1, softness, d) */
     const float alpha = 1.0f - t * t * (3.0f - 2.0f * t);
     if (op.flags & KF_CHROMA_MASK)
         return f4{alpha, alpha, alpha, 1.0f};
@@ -333,8 +338,11 @@ DEV f4 chroma_key(f4 c, const KOp& op)
 /* shader.frag:76-86 */
 DEV float levels1(float c, const KOp& op)
 {
-    float r = __builtin_fminf(__builtin_fmaxf(c - op.lv_min_input, 0.0f) * op.lv_inv_range, 1.0f);
-    r       = __builtin_amdgcn_exp2f(op.lv_inv_gamma * __builtin_amdgcn_logf(r)); /* pow(r, 1/gamma), r in [0,1] */
+    float r = __builtin_fminf(div_const(__builtin_fmaxf(c - op.lv_min_input, 0.0f), op.lv_range, op.lv_inv_range), 1.0f);
+    /* pow(r, 1/gamma), r in [0,1]. gamma == 1 (levels used for their ranges only) is exactly r; the log/exp pair
+       would be a few ulp off it, enough to move one 8-bit sample in ~10^5 (found by tests/test_fuzz.py). */
+    if (op.lv_inv_gamma != 1.0f)
+        r = __builtin_amdgcn_exp2f(op.lv_inv_gamma * __builtin_amdgcn_logf(r));
     if (op.lv_min_output == 0.0f && op.lv_max_output == 1.0f)
         return r; /* mix(0, 1, r) = 0*(1-r) + 1*r is exactly r */
     return mixf(op.lv_min_output, op.lv_max_output, r);

@@ -98,6 +98,11 @@ struct KOp {
     float   ch_inv_spill, ch_inv_soft; /* 1/ch_spill, 1/(ch_softness - 1) */
     int32_t sample_class; /* KSampleClass */
     int32_t csx, csy; /* FC_PLANAR: chroma planes are 1/2 width (csx) and/or 1/2 height (csy) of plane 0 */
+    /* divisors of the shader's per-pixel divisions by uniforms, next to their reciprocals above: x / c is evaluated as
+       div_const(x, c, 1/c), correctly rounded; x * (1/c) alone is an ulp off in a third of the cases and, with round
+       numbers like levels 0.1 / 0.9, moved 1 % of 8-bit samples (tests/test_fuzz.py) */
+    float lv_range;      /* max_input - min_input */
+    float ch_soft_range; /* ch_softness - 1 */
     KPlane  planes[4];
     KTri    tri[2];
 };

@@ -307,13 +307,15 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
         op.ch_spill            = (float)(t.chroma_spill_suppress / 360.0);
         op.ch_spill_saturation = (float)t.chroma_spill_suppress_saturation;
         op.ch_inv_spill        = 1.0f / op.ch_spill; /* +inf for 0: |diff| * inf keeps the shader's x/0 behaviour */
-        op.ch_inv_soft         = 1.0f / (op.ch_softness - 1.0f);
+        op.ch_soft_range       = op.ch_softness - 1.0f;
+        op.ch_inv_soft         = 1.0f / op.ch_soft_range;
     }
     if (t.levels_min_input > epsilon || t.levels_max_input < 1.0 - epsilon || t.levels_min_output > epsilon ||
         t.levels_max_output < 1.0 - epsilon || std::fabs(t.levels_gamma - 1.0) > epsilon) { /* :282-293 */
         op.flags |= KF_LEVELS;
         op.lv_min_input  = (float)t.levels_min_input;
-        op.lv_inv_range  = 1.0f / ((float)t.levels_max_input - (float)t.levels_min_input);
+        op.lv_range      = (float)t.levels_max_input - (float)t.levels_min_input;
+        op.lv_inv_range  = 1.0f / op.lv_range;
         op.lv_inv_gamma  = 1.0f / (float)t.levels_gamma;
         op.lv_min_output = (float)t.levels_min_output;
         op.lv_max_output = (float)t.levels_max_output;

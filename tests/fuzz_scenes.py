@@ -1,0 +1,105 @@
+"""Seeded random scenes for the fuzz tests: layer stacks that combine what the fixed suite tests one at a time
+(pixel formats x geometry x adjustments x keys / mix / blend modes x output sizes)."""
+import random
+
+import scenes as S
+
+FORMATS = ["bgra", "rgba", "argb", "abgr", "gray", "luma", "bgr", "rgb", "uyvy", "ycbcr420", "ycbcr422", "ycbcr444",
+           "ycbcra444", "ycbcra422"]
+
+
+def _source(rng, W, H, bits, seed):
+    f = rng.choice(FORMATS)
+    kind = rng.choice(["smooth", "noise", "video", "premul"])
+    # source size: the frame's, or something unrelated (scaled by the quad)
+    if rng.random() < 0.5:
+        w, h = W, H
+    else:
+        w, h = rng.choice([16, 24, 40, 48, 64, 90]), rng.choice([8, 16, 30, 32, 50])
+    if f in ("bgra", "rgba", "argb", "abgr"):
+        return S.frame(f, [(w, h, 4, kind if kind != "video" else "premul", seed)], bits)
+    if kind == "premul":
+        kind = "smooth"
+    if f in ("gray", "luma"):
+        return S.frame(f, [(w, h, 1, kind, seed)], bits)
+    if f in ("bgr", "rgb"):
+        return S.frame(f, [(w, h, 3, kind, seed)], bits)
+    if f == "uyvy":
+        w += w & 1
+        return S.frame("uyvy", [(w, h, 2, kind, seed)], bits)
+    sub = f[-3:]
+    w += w & 1
+    h += h & 1
+    return S.ycbcr(w, h, sub, kind, seed, bits=bits, alpha=f.startswith("ycbcra"))
+
+
+def _transform(rng, allow_blend=True):
+    t = {}
+    r = rng.random
+    if r() < 0.6:
+        t["opacity"] = rng.choice([1.0, 0.5, 0.25, round(r(), 3), 0.73])
+    if r() < 0.5:
+        t["fill_scale"] = [round(rng.uniform(0.2, 1.4), 3), round(rng.uniform(0.2, 1.4), 3)]
+        if r() < 0.15:
+            t["fill_scale"][0] = -t["fill_scale"][0]  # mirrored
+    if r() < 0.5:
+        t["fill_translation"] = [round(rng.uniform(-0.3, 0.7), 3), round(rng.uniform(-0.3, 0.7), 3)]
+    if r() < 0.25:
+        t["angle"] = round(rng.uniform(-1.0, 1.0), 3)
+        if r() < 0.5:
+            t["anchor"] = [round(r(), 2), round(r(), 2)]
+    if r() < 0.25:
+        t["crop_ul"] = [round(rng.uniform(0, 0.3), 3), round(rng.uniform(0, 0.3), 3)]
+        t["crop_lr"] = [round(rng.uniform(0.6, 1.0), 3), round(rng.uniform(0.6, 1.0), 3)]
+    if r() < 0.2:
+        t["clip_translation"] = [round(rng.uniform(0, 0.4), 3), round(rng.uniform(0, 0.4), 3)]
+        t["clip_scale"] = [round(rng.uniform(0.2, 0.9), 3), round(rng.uniform(0.2, 0.9), 3)]
+    if r() < 0.2:
+        d = lambda: round(rng.uniform(-0.12, 0.12), 3)
+        t.update(pers_ul=[d(), d()], pers_ur=[1 + d(), d()], pers_lr=[1 + d(), 1 + d()], pers_ll=[d(), 1 + d()])
+    if r() < 0.2:
+        t.update(levels_min_input=round(rng.uniform(0, 0.2), 3), levels_max_input=round(rng.uniform(0.7, 1.0), 3),
+                 levels_gamma=rng.choice([1.0, 0.6, 1.2, 2.2]), levels_min_output=rng.choice([0.0, 0.1]),
+                 levels_max_output=rng.choice([1.0, 0.9]))
+    if r() < 0.2:
+        t.update(brightness=round(rng.uniform(0.6, 1.4), 2), saturation=round(rng.uniform(0.0, 1.6), 2),
+                 contrast=round(rng.uniform(0.6, 1.4), 2))
+    if r() < 0.15:
+        t.update(dict(S.CHROMA, chroma_target_hue=rng.choice([120.0, 240.0, 30.0]),
+                      chroma_show_mask=1 if r() < 0.2 else 0))
+    if r() < 0.1:
+        t["invert"] = 1
+    if allow_blend and r() < 0.3:
+        t["blend_mode"] = rng.choice(S.BLEND_NAMES)
+    return t
+
+
+def fuzz_scene(seed, bits=8):
+    rng = random.Random(1000003 * seed + bits)
+    W, H = rng.choice([(96, 64), (100, 37), (64, 48), (130, 50), (48, 90), (256, 36)])
+    field_mode = rng.choice([0, 0, 0, 1, 2])
+    ops = []
+    nl = rng.randint(1, 6)
+    s = 7000 + 97 * seed
+    for i in range(nl):
+        kind = rng.random()
+        if kind < 0.12:  # key layer followed by its fill
+            ops.append(S.layer(_source(rng, W, H, bits, s + 10 * i), is_key=1, **_transform(rng, False)))
+            ops.append(S.layer(_source(rng, W, H, bits, s + 10 * i + 1), **_transform(rng)))
+        elif kind < 0.22:  # mix pair inside one layer
+            d = round(rng.random(), 2)
+            t = _transform(rng)
+            t["layer_depth"] = 1
+            ops.append([("push", t),
+                        ("push", dict(is_mix=1, opacity=1.0 - d)), ("visit", _source(rng, W, H, bits, s + 10 * i + 2)), ("pop",),
+                        ("push", dict(is_mix=1, opacity=d)), ("visit", _source(rng, W, H, bits, s + 10 * i + 3)), ("pop",),
+                        ("pop",)])
+        elif kind < 0.3:  # local key + fill in one layer
+            ops.append([("push", dict(layer_depth=1, **({"blend_mode": rng.choice(S.BLEND_NAMES)} if rng.random() < 0.5 else {}))),
+                        ("push", dict(is_key=1)), ("visit", _source(rng, W, H, bits, s + 10 * i + 4)), ("pop",),
+                        ("push", _transform(rng, False)), ("visit", _source(rng, W, H, bits, s + 10 * i + 5)), ("pop",),
+                        ("pop",)])
+        else:
+            ops.append(S.layer(_source(rng, W, H, bits, s + 10 * i + 6), **_transform(rng)))
+    square = rng.choice([None, None, (W * 4 // 3, H)])
+    return S.scene("fuzz_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, square=square, field_mode=field_mode)
