@@ -667,18 +667,19 @@ struct HotG {
     uint64_t ptr0, ptr1, ptr2, ptr3;
     int32_t  w0, h0, w1, h1;
     float    fw0, fh0, fw1, fh1;
+    int32_t  bits0;
 };
 DEV HotG load_hot_g(const KOp& op)
 {
     HotG h = {op.kind, op.flags, op.dst, op.src_surface, op.local_key, op.layer_key, op.pixel_format, op.x0, op.y0, op.x1,
               op.y1, op.unit_dx, op.unit_dy, op.sample_class, (uint64_t)op.planes[0].ptr, (uint64_t)op.planes[1].ptr,
               (uint64_t)op.planes[2].ptr, (uint64_t)op.planes[3].ptr, op.planes[0].w, op.planes[0].h, op.planes[1].w,
-              op.planes[1].h, op.planes[0].fw, op.planes[0].fh, op.planes[1].fw, op.planes[1].fh};
+              op.planes[1].h, op.planes[0].fw, op.planes[0].fh, op.planes[1].fw, op.planes[1].fh, op.planes[0].bits};
     asm volatile(""
                  : "+s"(h.kind), "+s"(h.flags), "+s"(h.dst), "+s"(h.src_surface), "+s"(h.local_key), "+s"(h.layer_key),
                    "+s"(h.pixel_format), "+s"(h.x0), "+s"(h.y0), "+s"(h.x1), "+s"(h.y1), "+s"(h.unit_dx), "+s"(h.unit_dy),
                    "+s"(h.sample_class), "+s"(h.ptr0), "+s"(h.ptr1), "+s"(h.ptr2), "+s"(h.ptr3), "+s"(h.w0), "+s"(h.h0),
-                   "+s"(h.w1), "+s"(h.h1), "+s"(h.fw0), "+s"(h.fh0), "+s"(h.fw1), "+s"(h.fh1));
+                   "+s"(h.w1), "+s"(h.h1), "+s"(h.fw0), "+s"(h.fh0), "+s"(h.fw1), "+s"(h.fh1), "+s"(h.bits0));
     return h;
 }
 
@@ -716,6 +717,10 @@ DEV f4 source_color_class(const KOp& op, const HotG& h, float s, float t, int px
 /* Source colour of a KOP_DRAW_PLANES at pixel (x,y); false when the pixel centre is outside the quad. */
 DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
 {
+    /* 1:1 sources are addressed by texel index in BOTH kernels, whatever the bit depth. For 16-bit sources the
+       reference pipeline under llvmpipe filters with fp32 weights from coordinates a few ulp off the texel centre,
+       i.e. mixes in ~1e-6 of a neighbour (1 LSB16 on ~1 % of samples; GPUs with fixed-point weights do not): taking
+       the exact texel keeps this kernel and cghip_composite_fast identical on the layers they share. */
     if (h.flags & KF_UNIT_SCALE) {
         const int px = x + h.unit_dx, py = y + h.unit_dy;
         color = h.sample_class != SC_GENERIC ? source_color_class<true>(op, h, 0.0f, 0.0f, px, py)

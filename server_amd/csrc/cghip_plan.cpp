@@ -290,8 +290,11 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
     op.pixel_format = from_surface ? (int)CGHIP_PF_BGRA : d.pixel_format;
     op.nplanes      = from_surface ? 0 : d.nplanes;
     op.blend_mode   = t.is_key ? CGHIP_BLEND_NORMAL : d.blend_mode; /* :270-272 */
-    if (op.blend_mode == 12 || op.blend_mode >= 29 || op.blend_mode < 0)
-        op.blend_mode = 0; /* shader.frag:403,421: soft_light and mix execute BlendNormal */
+    /* shader.frag:403,421: soft_light (12) and mix (>= 29) execute BlendNormal INSIDE `if (blend_mode != 0)`: the
+       colour still goes through fore.rgb / (fore.a + 1e-7) * fore.a, which is not the identity (an inverted opaque
+       source has a = 0, rgb != 0 and comes out black). So the mode is kept; get_blend_color's default is BlendNormal. */
+    if (op.blend_mode < 0)
+        op.blend_mode = 0;
     op.opacity = (float)(t.is_key ? 1.0 : t.opacity); /* :252 */
     if (d.keyer == CGHIP_KEYER_ADDITIVE)
         op.flags |= KF_ADDITIVE;

@@ -47,8 +47,11 @@ def oracle_log(sc):
         m.close()
 
 
-def executed_mode(mode):  # shader.frag:389-421 aliasing
-    return 0 if (mode == 12 or mode >= 29 or mode < 0) else mode
+def executed_mode(mode):
+    """The planner keeps the reference's mode number: soft_light (12) and mix (29) execute BlendNormal, but inside
+    `if (blend_mode != 0)` (shader.frag:403,421,427), i.e. with the un-premultiply / re-premultiply round trip that
+    mode 0 skips. Only a negative mode (the oracle's 'no blend()' marker) maps to 0."""
+    return 0 if mode < 0 else mode
 
 
 @pytest.mark.parametrize("sc", SCENES, ids=[s["name"] for s in SCENES])
