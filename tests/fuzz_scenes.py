@@ -103,3 +103,48 @@ def fuzz_scene(seed, bits=8):
             ops.append(S.layer(_source(rng, W, H, bits, s + 10 * i + 6), **_transform(rng)))
     square = rng.choice([None, None, (W * 4 // 3, H)])
     return S.scene("fuzz_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, square=square, field_mode=field_mode)
+
+
+def fuzz_fast_scene(seed, bits=8):
+    """Random stacks the 4-pixels-per-lane kernel accepts: unit-scale layers of the frame's size (optionally cropped
+    or clipped on 4-pixel boundaries), normal blend, keys, every adjustment."""
+    rng = random.Random(7000003 * seed + bits)
+    W, H = rng.choice([(96, 64), (128, 36), (260, 50), (516, 22), (64, 90)])
+    ops = []
+    s = 9000 + 131 * seed
+    for i in range(rng.randint(1, 7)):
+        f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420"])
+        kind = rng.choice(["smooth", "noise", "video"])
+        if f in ("bgra", "rgba", "argb", "abgr"):
+            src = S.frame(f, [(W, H, 4, rng.choice(["premul", "noise", "smooth"]), s + i)], bits)
+        else:
+            src = S.ycbcr(W, H, f[-3:], kind, s + i, bits=bits, alpha=f.startswith("ycbcra"))
+        t = {}
+        r = rng.random
+        if r() < 0.7:
+            t["opacity"] = rng.choice([1.0, 0.5, 0.25, round(r(), 3), 0.73])
+        if r() < 0.3:  # crop on 4-pixel columns (any row)
+            x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
+            y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
+            if x1 > x0 and y1 > y0:
+                t["crop_ul"], t["crop_lr"] = [x0 / W, y0 / H], [x1 / W, y1 / H]
+        if r() < 0.2:
+            x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
+            y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
+            if x1 > x0 and y1 > y0:
+                t["clip_translation"], t["clip_scale"] = [x0 / W, y0 / H], [(x1 - x0) / W, (y1 - y0) / H]
+        if r() < 0.25:
+            t.update(levels_min_input=round(rng.uniform(0, 0.2), 3), levels_max_input=round(rng.uniform(0.7, 1.0), 3),
+                     levels_gamma=rng.choice([1.0, 1.0, 0.6, 1.2, 2.2]), levels_min_output=rng.choice([0.0, 0.1]),
+                     levels_max_output=rng.choice([1.0, 0.9]))
+        if r() < 0.2:
+            t.update(brightness=round(rng.uniform(0.6, 1.4), 2), saturation=round(rng.uniform(0.0, 1.6), 2),
+                     contrast=round(rng.uniform(0.6, 1.4), 2))
+        if r() < 0.2:
+            t.update(dict(S.CHROMA, chroma_target_hue=rng.choice([120.0, 240.0, 30.0]), chroma_show_mask=1 if r() < 0.2 else 0))
+        if r() < 0.1:
+            t["invert"] = 1
+        if r() < 0.25:
+            t["is_key"] = 1
+        ops.append(S.layer(src, **t))
+    return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))

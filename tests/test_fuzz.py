@@ -69,3 +69,40 @@ def test_hip_matches_oracle_on_random_scenes(mode):
     finally:
         m.close()
     print("worst over %d scenes (%s): %s" % (N_GPU, mode, worst))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
+def test_fast_kernel_on_random_unit_scale_stacks(bits):
+    """Random stacks of the class cghip_composite_fast runs: it must equal the general kernel bit for bit at both
+    depths (same texel placement, same arithmetic), and the oracle bit for bit at 8 bits."""
+    import server_amd as A
+    from fuzz_scenes import fuzz_fast_scene
+    m = A.Mixer(channel_id=4, gpu=0)
+    L = A.lib()
+    ran_fast = 0
+    try:
+        for seed in range(300):
+            sc = fuzz_fast_scene(seed, bits)
+            cache = {}
+            fast = S.run_product(sc, mixer=m, planes_cache=cache)
+            L.cghip_debug_force_general_kernel(1)
+            try:
+                general = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_force_general_kernel(0)
+            assert np.array_equal(fast, general), (seed, S.diff_stats(fast, general))
+            ref = S.run_oracle(sc, "cpu", cache)
+            st = S.diff_stats(fast, ref)
+            if bits == 8:
+                pow_used = any(o[0] == "push" and o[1].get("levels_gamma", 1.0) != 1.0 for o in sc["ops"])
+                if pow_used:  # v_log_f32 / v_exp_f32 here, libm powf in the oracle
+                    assert st["max"] <= 1 and st["gt0"] <= 1e-4, (seed, st)
+                else:
+                    assert st["max"] == 0, (seed, st)
+            else:
+                assert st["gt2"] <= 3e-2, (seed, st)
+            ran_fast += 1
+    finally:
+        m.close()
+    assert ran_fast == 300
