@@ -122,7 +122,7 @@ def test_device_resident_frame_path(mixer):
 
 def test_fast_kernel_equals_general_kernel(mixer):
     """Frames made only of unit-scale normal-blend layers run the 4-pixels-per-lane kernel; it must agree with the
-    general kernel to the last bit on 8-bit sources and within fp32-weight noise (1 LSB16) on 16-bit ones."""
+    general kernel to the last bit at both depths."""
     import server_amd as A
     L = A.lib()
     W, H = 776, 142  # neither a multiple of 256 nor of 4 rows: exercises edge lanes
@@ -142,10 +142,7 @@ def test_fast_kernel_equals_general_kernel(mixer):
         finally:
             L.cghip_debug_force_general_kernel(0)
         st = S.diff_stats(fast, general)
-        if bits == 8:
-            assert st["max"] == 0, st
-        else:
-            assert st["gt1"] <= 1e-4 and st["gt0"] <= 2e-2, st
+        assert st["max"] == 0, st  # both kernels address 1:1 sources by texel index and share the arithmetic
         ref = S.run_oracle(sc, "cpu")
         so = S.diff_stats(fast, ref)
         assert (so["max"] <= 1 and so["gt0"] <= 1e-4) if bits == 8 else (so["gt2"] <= 1e-4), so
