@@ -1189,11 +1189,13 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         const HotOp h   = load_hot(op);
         const bool  clr = h.kind == KOP_CLEAR;
         const bool  clr0 = clr & (h.dst == KS_KEY0), clr1 = clr & (h.dst == KS_KEY1);
-        static_for<0, P>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            K0[i] = clr0 ? 0.0f : K0[i];
-            K1[i] = clr1 ? 0.0f : K1[i];
-        });
+        if (clr) { /* wave-uniform; the selects stay inside so that draws do not pay for them */
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                K0[i] = clr0 ? 0.0f : K0[i];
+                K1[i] = clr1 ? 0.0f : K1[i];
+            });
+        }
         /* one combined test, one merge point: a chain of early `continue`s made the compiler copy all 24
            loop-carried registers at every exit. x0, x1 are multiples of 4: a lane is all in or all out. */
         if (clr | !((y >= h.y0) & (y < h.y1) & (px0 >= h.x0) & (px0 < h.x1)))

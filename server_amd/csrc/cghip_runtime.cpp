@@ -247,6 +247,9 @@ static int plane_new(cghip_device* dev, int width, int height, int channels, int
         return fail(CGHIP_ERR_INVALID, "bad arguments");
     if (width <= 0 || height <= 0 || channels < 1 || channels > 4 || (bits != 8 && bits != 16))
         return fail(CGHIP_ERR_INVALID, "plane needs width,height > 0, 1..4 channels, 8 or 16 bits (device.cpp:196-197)");
+    /* the kernels address texels with 32-bit byte offsets from the plane (or row) base */
+    if ((unsigned long long)width * (unsigned long long)height * channels * (bits / 8) > 0xFFFFFFF0ull)
+        return fail(CGHIP_ERR_UNSUPPORTED, "plane larger than 4 GiB");
     cghip_plane* p = new cghip_plane();
     p->dev = dev, p->width = width, p->height = height, p->channels = channels, p->bits = bits;
     p->bytes = (size_t)width * height * channels * (bits / 8);
