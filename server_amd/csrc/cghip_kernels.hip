@@ -796,14 +796,15 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
         {
             /* CLEAR as selects and ONE skip test: every early `continue` made the compiler copy all loop-carried
                surface registers at that exit (see cghip_composite_fast) */
-            const bool c1 = clr & (h.dst == KS_RGBA1), c2 = clr & (h.dst == KS_RGBA2);
-            const bool c3 = clr & (h.dst == KS_KEY0), c4 = clr & (h.dst == KS_KEY1);
-            if (FULL) {
-                s1 = sel4(c1, f4{0, 0, 0, 0}, s1);
-                s2 = sel4(c2, f4{0, 0, 0, 0}, s2);
+            const bool c1 = h.dst == KS_RGBA1, c2 = h.dst == KS_RGBA2, c3 = h.dst == KS_KEY0, c4 = h.dst == KS_KEY1;
+            if (clr) { /* wave-uniform; draws do not pay for the selects */
+                if (FULL) {
+                    s1 = sel4(c1, f4{0, 0, 0, 0}, s1);
+                    s2 = sel4(c2, f4{0, 0, 0, 0}, s2);
+                }
+                k0 = c3 ? 0.0f : k0;
+                k1 = c4 ? 0.0f : k1;
             }
-            k0 = c3 ? 0.0f : k0;
-            k1 = c4 ? 0.0f : k1;
         }
         /* cull against the op's touched box, then against the quad itself */
         bool live = !clr & (y >= h.y0) & (y < h.y1) & (x >= h.x0) & (x < h.x1);
