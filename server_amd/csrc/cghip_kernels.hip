@@ -1094,17 +1094,31 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
 
 /* shader.frag:532-541 for four pixels onto the RGBA target. SIMPLE: no keys, no invert, linear keyer: the
  * neutral-operand steps of shade_blend() dropped (x*1, fma(x,1,0) are exact, so the results are the same). */
-template <int BITS, bool SIMPLE>
+/* VARIANT 0: no keys, no invert, linear keyer. 1: exactly one key (local or layer), else like 0: the usual keyed
+ * fill. 2: everything, optional steps made unconditional with neutral operands. */
+template <int BITS, int VARIANT>
 DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
 {
 #pragma clang fp contract(off)
     float opa = op.opacity;
     asm volatile("" : "+v"(opa)); /* VALU ops with an SGPR operand issue at ~2/3 rate (tests/ubench): one v_mov instead */
-    if (SIMPLE) {
+    if (VARIANT == 0) {
         static_for<0, 4>([&](auto I) {
             constexpr int i  = decltype(I)::value;
             const f4      f  = {col[i].x * opa, col[i].y * opa, col[i].z * opa, col[i].w * opa};
             const float   ia = 1.0f - f.w;
+            S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
+                      quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
+        });
+    } else if (VARIANT == 1) {
+        const bool from1 = (op.local_key != KS_NONE ? op.local_key : op.layer_key) == KS_KEY1;
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const float   k = from1 ? K1[i] : K0[i];
+            f4            c = col[i];
+            c.x *= k, c.y *= k, c.z *= k, c.w *= k;
+            const f4    f  = {c.x * opa, c.y * opa, c.z * opa, c.w * opa};
+            const float ia = 1.0f - f.w;
             S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
                       quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
         });
@@ -1242,10 +1256,14 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
             else
                 blend_key4<BITS, false>(h, col, K0, K1);
         } else {
+            const bool plain_keyer = !(h.flags & (KF_INVERT | KF_ADDITIVE));
+            const bool one_key     = (h.local_key != KS_NONE) != (h.layer_key != KS_NONE);
             if (simple)
-                blend_rgba4<BITS, true>(h, col, S, K0, K1);
+                blend_rgba4<BITS, 0>(h, col, S, K0, K1);
+            else if (plain_keyer && one_key)
+                blend_rgba4<BITS, 1>(h, col, S, K0, K1);
             else
-                blend_rgba4<BITS, false>(h, col, S, K0, K1);
+                blend_rgba4<BITS, 2>(h, col, S, K0, K1);
         }
     }
 
