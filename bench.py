@@ -11,7 +11,7 @@ reported separately as `end_to_end_fps` (pinned H2D of every plane + D2H of the 
 Multi-GPU: channels shard by GPU with no data-path collective: rank r drives its own channel on GPU
 LOCAL_RANK; value = N frames per step-time (weak scaling). torch.distributed is only the barrier + max-reduce.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -185,11 +185,14 @@ def cpu_baseline(S, scene, budget_s=12.0):
                       % (n, scene["name"])}
 
 
+SETTLE_S = 0.5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="config3_16bit", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -206,6 +209,12 @@ def main():
     scene = WORKLOADS[args.workload](S)
     ch = Channel(A, S, scene, gpu, channel_id=rank + 1)
 
+    # The GPU needs a few hundred milliseconds of load before its clocks settle (the same launch takes 0.33 ms in the
+    # first 50 frames after idle and 0.28 ms from then on: tests/gpu_occupancy.py). Untimed, before the W warmup
+    # steps, and reported as config.settle_s.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < SETTLE_S:
+        run_steps(ch, 20)
     run_steps(ch, max(1, args.warmup))
     device_sync()
     barrier()
@@ -264,7 +273,7 @@ def main():
             "config": {"workload": "%s: %dx%d, %d layers, %d-bit out" % (
                 scene["name"], scene["width"], scene["height"],
                 sum(1 for o in scene["ops"] if o[0] == "visit"), scene["bits"]),
-                "channels_per_gpu": 1, "frames_in_flight": 2, "parallelism": "channel-sharded x%d" % world},
+                "channels_per_gpu": 1, "frames_in_flight": 2, "settle_s": SETTLE_S, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "cghip_composite_fast<%d>" % scene["bits"] if args.workload in ("config3_16bit", "config3_8bit", "config1")

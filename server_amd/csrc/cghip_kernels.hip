@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     constexpr int P    = 4;
     const int     lane = threadIdx.x & 63;
     const int     wave = threadIdx.x >> 6;
-    const int     y    = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave); /* wave-uniform: keep it scalar */
+    const int     y    = __builtin_amdgcn_readfirstlane(blockIdx.y * (blockDim.x >> 6) + wave); /* wave-uniform: keep it scalar */
     if (y >= H)
         return;
     const int px0 = blockIdx.x * 64 * P + lane * P;
@@ -1309,6 +1309,8 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
 
 static int g_force_general = 0;
 static int g_pad_lds       = 0;
+static unsigned g_fast_rows = 4;
+extern "C" void cghip_debug_fast_rows(int rows) { g_fast_rows = rows >= 1 && rows <= 4 ? (unsigned)rows : 4u; }
 extern "C" void cghip_debug_force_general_kernel(int on) { g_force_general = on; }
 /* occupancy experiments: dynamic LDS nobody touches, to cap the workgroups resident on a CU (160 KB per CU) */
 extern "C" void cghip_debug_pad_lds(int bytes) { g_pad_lds = bytes; }
@@ -1318,7 +1320,9 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
 {
     dim3 block(256);
     if (fast && !full && !g_force_general) {
-        dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4));
+        const unsigned rows = g_fast_rows; /* rows (= waves) per workgroup */
+        block = dim3(64 * rows);
+        dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + rows - 1) / rows));
         if (bits == 8)
             hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
         else

@@ -11,10 +11,15 @@ L = A.lib()
 L.cghip_debug_pad_lds.argtypes = [__import__("ctypes").c_int]
 sc = S.config3(bits=16)
 ch = Channel(A, S, sc, 0, 1)
-for kb in (0, 32, 40, 53, 64, 80):
-    L.cghip_debug_pad_lds(kb * 1024)
-    run_steps(ch, 3)
-    ms = run_steps(ch, 20)
-    print("LDS pad %3d KB -> <= %d workgroups (waves per SIMD) per CU: kernel %.3f ms" % (kb, 160 // kb if kb else 8, np.mean(ms)), flush=True)
+L.cghip_debug_fast_rows.argtypes = [__import__("ctypes").c_int]
+run_steps(ch, 200)  # let the clocks settle
+for rep in range(3):
+    for rows, kb in ((4, 0), (1, 0), (2, 0), (4, 32), (4, 40), (4, 0)):
+        L.cghip_debug_fast_rows(rows)
+        L.cghip_debug_pad_lds(kb * 1024)
+        run_steps(ch, 5)
+        ms = run_steps(ch, 60)
+        print("rep %d rows/wg %d  LDS pad %2d KB: kernel %.3f ms (min %.3f)" % (rep, rows, kb, np.mean(ms), np.min(ms)), flush=True)
+L.cghip_debug_fast_rows(4)
 L.cghip_debug_pad_lds(0)
 ch.close()
