@@ -25,6 +25,8 @@ void cghip_debug_force_general_kernel(int on);
 /* Launches the 4-pixels-per-lane kernel with this much unused dynamic LDS, which caps the workgroups resident on a
  * CU (160 KB each): occupancy experiments only (tests/gpu_occupancy.py). 0 = off. */
 void cghip_debug_pad_lds(int bytes);
+/* Rows (= waves) per workgroup of the 4-pixels-per-lane kernel, 1..4 (default 4): launch-shape experiments. */
+void cghip_debug_fast_rows(int rows);
 
 #ifdef __cplusplus
 }

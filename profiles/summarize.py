@@ -30,6 +30,16 @@ def counters(sub):
 shutil.copy(find("stats", "_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_stats.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
 bench = json.load(open(os.path.join(src, "bench_stats.json")))
+# bench.py runs an untimed clock-settle phase and W warmup steps before its K timed steps; the --stats average covers
+# all of those launches. The timed region is the LAST K launches of the trace: average them separately.
+trace = [r for r in csv.DictReader(open(find("stats", "_kernel_trace.csv"))) if "cghip_composite" in r["Kernel_Name"]]
+trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace]
+k = bench["steps"]
+json.dump({"launches_in_trace": len(durs), "avg_ns_all": sum(durs) / len(durs), "timed_steps": k,
+           "avg_ns_last_timed_steps": sum(durs[-k:]) / len(durs[-k:]), "min_ns": min(durs), "max_ns": max(durs),
+           "bench_avg_kernel_ms": bench["roofline"]["avg_kernel_ms"]},
+          open(os.path.join(dst, tag + "_kernel_timed_region.json"), "w"), indent=1)
 workload = bench["config"]["workload"].split(":")[0]
 
 f, kernel = counters("fetch")
