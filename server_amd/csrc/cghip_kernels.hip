@@ -309,7 +309,8 @@ DEV f3 hsv2rgb(f3 c)
 }
 
 /* shader.frag:323-383,436-439; colour in internal order */
-DEV f4 chroma_key(f4 c, const KOp& op)
+template <class P>
+DEV f4 chroma_key(f4 c, const P& op)
 {
     const f3    hsv      = rgb2hsv(f3{c.z, c.y, c.x}); /* c.bgra -> real r,g,b */
     const float hueDiff  = (0.5f - __builtin_fabsf(__builtin_fabsf(hsv.x - op.ch_target_hue) - 0.5f)) * 2.0f;
@@ -336,7 +337,8 @@ DEV f4 chroma_key(f4 c, const KOp& op)
 }
 
 /* shader.frag:76-86 */
-DEV float levels1(float c, const KOp& op)
+template <class P>
+DEV float levels1(float c, const P& op)
 {
     float r = __builtin_fminf(div_const(__builtin_fmaxf(c - op.lv_min_input, 0.0f), op.lv_range, op.lv_inv_range), 1.0f);
     /* pow(r, 1/gamma), r in [0,1]. gamma == 1 (levels used for their ranges only) is exactly r; the log/exp pair
@@ -349,7 +351,8 @@ DEV float levels1(float c, const KOp& op)
 }
 
 /* shader.frag:48-70 */
-DEV void csb(f4& color, const KOp& op)
+template <class P>
+DEV void csb(f4& color, const P& op)
 {
     const bool hd = op.flags & KF_IS_HD;
     const f3   L  = hd ? f3{0.0722f, 0.7152f, 0.2126f} : f3{0.114f, 0.587f, 0.299f};
@@ -857,6 +860,41 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
     }
 }
 
+/* Adjustment parameters copied into VGPRs once per op, for the 4-pixels-per-lane kernel: a VALU instruction with an
+ * SGPR operand issues at half rate on gfx950 (tests/ubench/valu_rate: v_mul_f32 v, s, v 1.8 ns vs 1.0 ns), and each
+ * of these is used 4..16 times per lane and op. Same field names as KOp, so the shader functions take either. */
+DEV float in_vgpr(float x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+struct LevelsV {
+    float lv_min_input, lv_range, lv_inv_range, lv_inv_gamma, lv_min_output, lv_max_output;
+    explicit DEV LevelsV(const KOp& o)
+        : lv_min_input(in_vgpr(o.lv_min_input)), lv_range(in_vgpr(o.lv_range)), lv_inv_range(in_vgpr(o.lv_inv_range)),
+          lv_inv_gamma(o.lv_inv_gamma), lv_min_output(o.lv_min_output), lv_max_output(o.lv_max_output)
+    { /* gamma and the output range feed wave-uniform tests first: they stay scalar until used */
+    }
+};
+struct ChromaV {
+    float    ch_target_hue, ch_hue_width, ch_min_saturation, ch_min_brightness, ch_spill, ch_inv_spill,
+        ch_spill_saturation, ch_soft_range, ch_inv_soft;
+    uint32_t flags;
+    explicit DEV ChromaV(const KOp& o)
+        : ch_target_hue(in_vgpr(o.ch_target_hue)), ch_hue_width(in_vgpr(o.ch_hue_width)),
+          ch_min_saturation(in_vgpr(o.ch_min_saturation)), ch_min_brightness(in_vgpr(o.ch_min_brightness)),
+          ch_spill(in_vgpr(o.ch_spill)), ch_inv_spill(in_vgpr(o.ch_inv_spill)),
+          ch_spill_saturation(in_vgpr(o.ch_spill_saturation)), ch_soft_range(in_vgpr(o.ch_soft_range)),
+          ch_inv_soft(in_vgpr(o.ch_inv_soft)), flags(o.flags)
+    {
+    }
+};
+struct CsbV {
+    float    brt, sat, con;
+    uint32_t flags;
+    explicit DEV CsbV(const KOp& o) : brt(in_vgpr(o.brt)), sat(in_vgpr(o.sat)), con(in_vgpr(o.con)), flags(o.flags) {}
+};
+
 /* ------------------------------------------------------------------ the fast compositor */
 
 /* Fast compositor: frames whose every draw is a unit-scale, normal-blend layer whose pixel box and source offset
@@ -1238,16 +1276,19 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         }
         /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
         if (h.flags & KF_CHROMA) {
-            static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key(col[decltype(I)::value], op); });
+            const ChromaV cp(op);
+            static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key(col[decltype(I)::value], cp); });
         }
         if (h.flags & KF_LEVELS) {
+            const LevelsV lp(op);
             static_for<0, P>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                col[i].x = levels1(col[i].x, op), col[i].y = levels1(col[i].y, op), col[i].z = levels1(col[i].z, op);
+                col[i].x = levels1(col[i].x, lp), col[i].y = levels1(col[i].y, lp), col[i].z = levels1(col[i].z, lp);
             });
         }
         if (h.flags & KF_CSB) {
-            static_for<0, P>([&](auto I) { csb(col[decltype(I)::value], op); });
+            const CsbV bp(op);
+            static_for<0, P>([&](auto I) { csb(col[decltype(I)::value], bp); });
         }
         const bool simple = h.local_key == KS_NONE && h.layer_key == KS_NONE && !(h.flags & (KF_INVERT | KF_ADDITIVE));
         if (h.dst >= KS_KEY0) {
