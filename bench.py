@@ -47,15 +47,16 @@ def dist_setup(n_gpus):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     use_gpu = torch.cuda.is_available()
+    ndev = torch.cuda.device_count() if use_gpu else 0
     if use_gpu:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % ndev)  # a rehearsal may run more ranks than the box has GPUs
     backend = os.environ.get("CGHIP_DIST_BACKEND", "nccl" if use_gpu else "gloo")
     try:
         dist.init_process_group(backend=backend)
     except Exception:
         backend = "gloo"
         dist.init_process_group(backend=backend)
-    dev = torch.device("cuda", local_rank) if (backend == "nccl") else torch.device("cpu")
+    dev = torch.device("cuda", local_rank % ndev) if (backend == "nccl") else torch.device("cpu")
 
     def barrier():
         dist.barrier()
