@@ -113,7 +113,9 @@ typedef struct cghip_draw {
  * field renders themselves (modules/decklink/consumer/decklink_consumer.cpp:293-308,
  * modules/newtek/consumer/newtek_ndi_consumer.cpp:135-140). */
 #define CGHIP_RENDER_FIELD_ROWS_ONLY 0x2u
-#define CGHIP_MAX_SURFACES 16
+/* Surface slots one frame's draw list may name (slot 0 = the frame; every key / mix / layer temporary the renderer
+ * creates is one more). Slots are bound to the kernel's register surfaces by liveness, so this only bounds the list. */
+#define CGHIP_MAX_SURFACES 1024
 
 /* ---- error reporting ------------------------------------------------------------------------- */
 const char* cghip_last_error(void);

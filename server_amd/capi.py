@@ -334,7 +334,7 @@ class Mixer:
     def flatten(self, width, height, square_width=None, square_height=None, bits=8, field_mode=0):
         fmt = self._format(width, height, square_width, square_height, bits, field_mode)
         draws = (Draw * 256)()
-        surf = (Surface * 16)()
+        surf = (Surface * 1024)()  # CGHIP_MAX_SURFACES
         nd, ns = C.c_int(0), C.c_int(0)
         check_host(self.H.cghost_mixer_flatten(self.h, C.byref(fmt), draws, 256, C.byref(nd), surf, C.byref(ns)))
         return [draws[i] for i in range(nd.value)], [surf[i].channels for i in range(ns.value)]

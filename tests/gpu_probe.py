@@ -30,8 +30,8 @@ for bits in [int(b) for b in os.environ.get("PROBE_BITS", "16,8").split(",")]:
     for kind in which:
         sc = stack(kind, bits)
         ch = Channel(A, S, sc, 0, 1)
-        run_steps(ch, 2)
-        ms = run_steps(ch, 5)
+        run_steps(ch, int(os.environ.get("PROBE_SETTLE", "2")))
+        ms = run_steps(ch, 5 if "PROBE_SETTLE" not in os.environ else 50)
         b = S.algorithmic_bytes(sc)
         print("%-10s %2d-bit  %d layers  kernel %.3f ms  %.0f GB/s  (%.1f ns per Mlayer-px)" % (
             kind, bits, NL, np.mean(ms), b / np.mean(ms) / 1e6, np.mean(ms) * 1e6 / (NL * W * H / 1e6)), flush=True)

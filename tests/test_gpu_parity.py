@@ -298,3 +298,19 @@ def test_field_rows_only_readback(mixer):
         got = mixer.get(mixer.render_async(W, H, field_mode=mode, readback=2))
         assert np.array_equal(got[first::2], full[first::2])
         assert np.array_equal(full[first::2], S.run_oracle(sc, "cpu")[first::2])
+
+
+def test_long_rundown_with_many_key_layers(mixer):
+    """60 layers, 20 of them key layers each followed by its fill: more surface slots than the kernel has key
+    registers (bound by liveness), a long op list, and the fast kernel's loop over it."""
+    W, H = 128, 48
+    ops = []
+    for i in range(20):
+        ops.append(S.layer(S.ycbcr(W, H, "422", "smooth", 1200 + i), is_key=1))
+        ops.append(S.layer(S.bgra(W, H, "premul", 1300 + i), opacity=0.6))
+        ops.append(S.layer(S.ycbcr(W, H, "420", "video", 1400 + i), opacity=0.3, **(S.LEVELS if i % 2 else {})))
+    sc = S.scene("rundown", W, H, ops)
+    got = S.run_product(sc, mixer=mixer)
+    ref = S.run_oracle(sc, "cpu")
+    st = S.diff_stats(got, ref)
+    assert st["max"] <= 1 and st["gt0"] <= 1e-4, st  # levels gamma 1.2: v_log/v_exp vs powf

@@ -245,3 +245,18 @@ def test_dry_run_mixer_cannot_render():
     with pytest.raises(A.CGHIPError):
         m.render(8, 8)
     m.close()
+
+
+def test_many_key_layers_do_not_exhaust_surface_slots():
+    """Every is_key layer creates a fresh key texture in the reference (image_mixer.cpp:174-183); a rundown with 40
+    key + fill pairs names 41 surface slots, which the planner still binds to its two key registers by liveness."""
+    W, H = 64, 32
+    ops = []
+    for i in range(40):
+        ops.append(S.layer(S.bgra(W, H, "smooth", 900 + i), is_key=1))
+        ops.append(S.layer(S.bgra(W, H, "premul", 950 + i), opacity=0.9))
+    sc = S.scene("many_keys", W, H, ops)
+    draws, surfaces, kops, full = product_plan(sc)
+    assert len(surfaces) == 41 and not full
+    assert sum(1 for o in kops if o.kind != K.KOP_CLEAR) == 80
+    assert all(o.dst in (0, 3, 4) for o in kops)
