@@ -1216,7 +1216,10 @@ DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
     });
 }
 
-template <int BITS>
+/* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
+ * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
+ * either keyer) and item draws into them. Four waves per SIMD fit, which is enough here. */
+template <int BITS, bool FULL>
 __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
                                                             int W, int H, int field_mode)
 {
@@ -1228,11 +1231,11 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         return;
     const int px0 = blockIdx.x * 64 * P + lane * P;
 
-    f4    S[P];
+    f4    S[P], S1[P], S2[P];
     float K0[P], K1[P];
     static_for<0, P>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        S[i]  = f4{0, 0, 0, 0};
+        S[i] = S1[i] = S2[i] = f4{0, 0, 0, 0};
         K0[i] = K1[i] = 0.0f;
     });
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
@@ -1247,6 +1250,10 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
                 constexpr int i = decltype(I)::value;
                 K0[i] = clr0 ? 0.0f : K0[i];
                 K1[i] = clr1 ? 0.0f : K1[i];
+                if (FULL) {
+                    S1[i] = sel4(h.dst == KS_RGBA1, f4{0, 0, 0, 0}, S1[i]);
+                    S2[i] = sel4(h.dst == KS_RGBA2, f4{0, 0, 0, 0}, S2[i]);
+                }
             });
         }
         /* one combined test, one merge point: a chain of early `continue`s made the compiler copy all 24
@@ -1257,7 +1264,10 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         const bool s16 = h.bits0 == 16;
         const bool red_only = h.dst >= KS_KEY0 && !(h.flags & (KF_CHROMA | KF_LEVELS | KF_CSB));
         f4         col[P];
-        if (h.fast_class == FC_PACKED) {
+        if (FULL && h.kind == KOP_DRAW_SURFACE) {
+            const bool from2 = op.src_surface == KS_RGBA2;
+            static_for<0, P>([&](auto I) { col[decltype(I)::value] = sel4(from2, S2[decltype(I)::value], S1[decltype(I)::value]); });
+        } else if (h.fast_class == FC_PACKED) {
             if (s16)
                 fetch_packed<16>(h, sx, sy, col);
             else
@@ -1299,12 +1309,28 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         } else {
             const bool plain_keyer = !(h.flags & (KF_INVERT | KF_ADDITIVE));
             const bool one_key     = (h.local_key != KS_NONE) != (h.layer_key != KS_NONE);
-            if (simple)
-                blend_rgba4<BITS, 0>(h, col, S, K0, K1);
-            else if (plain_keyer && one_key)
-                blend_rgba4<BITS, 1>(h, col, S, K0, K1);
+            auto       blend_into  = [&](f4(&D)[P]) {
+                if (FULL && op.blend_mode != 0) { /* a layer temporary composited with its blend mode */
+                    static_for<0, P>([&](auto I) {
+                        constexpr int i    = decltype(I)::value;
+                        const float   lkey = h.local_key == KS_KEY1 ? K1[i] : K0[i];
+                        const float   ykey = h.layer_key == KS_KEY1 ? K1[i] : K0[i];
+                        const f4      r    = shade_blend<true>(op, col[i], lkey, ykey, D[i]);
+                        D[i] = f4{quantize<BITS>(r.x), quantize<BITS>(r.y), quantize<BITS>(r.z), quantize<BITS>(r.w)};
+                    });
+                } else if (simple)
+                    blend_rgba4<BITS, 0>(h, col, D, K0, K1);
+                else if (plain_keyer && one_key)
+                    blend_rgba4<BITS, 1>(h, col, D, K0, K1);
+                else
+                    blend_rgba4<BITS, 2>(h, col, D, K0, K1);
+            };
+            if (!FULL || h.dst == KS_RGBA0)
+                blend_into(S);
+            else if (h.dst == KS_RGBA1)
+                blend_into(S1);
             else
-                blend_rgba4<BITS, 2>(h, col, S, K0, K1);
+                blend_into(S2);
         }
     }
 
@@ -1360,14 +1386,18 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
                                              int field_mode, int full, int fast, hipStream_t stream)
 {
     dim3 block(256);
-    if (fast && !full && !g_force_general) {
+    if (fast && !g_force_general) {
         const unsigned rows = g_fast_rows; /* rows (= waves) per workgroup */
         block = dim3(64 * rows);
         dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + rows - 1) / rows));
-        if (bits == 8)
-            hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+        if (bits == 8 && !full)
+            hipLaunchKernelGGL((cghip_composite_fast<8, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+        else if (bits == 8)
+            hipLaunchKernelGGL((cghip_composite_fast<8, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+        else if (!full)
+            hipLaunchKernelGGL((cghip_composite_fast<16, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
         else
-            hipLaunchKernelGGL((cghip_composite_fast<16>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<16, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
         return hipGetLastError();
     }
     dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4));

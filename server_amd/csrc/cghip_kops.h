@@ -35,7 +35,8 @@ enum KOpFlags : uint32_t {
 enum KFastClass : int32_t {
     FC_NONE   = 0,
     FC_PACKED = 1, /* one 4-channel plane (bgra / rgba / argb / abgr), unit scale */
-    FC_PLANAR = 2  /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
+    FC_PLANAR = 2, /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
+    FC_SURFACE = 3 /* KOP_DRAW_SURFACE: a layer / mix temporary composited 1:1 (any blend mode, either keyer) */
 };
 
 /* How cghip_composite samples a KOP_DRAW_PLANES source (host classification, cghip_plan.cpp). The two common

@@ -186,14 +186,20 @@ int floor_div256(int64_t v) { return (int)((v >= 0) ? v / 256 : -((-v + 255) / 2
 
 /* Which draws the 4-pixels-per-lane kernel (cghip_composite_fast) can run: unit-scale sources whose texels
  * can be fetched with aligned vector loads, normal blend into the frame or a key surface. */
-static void classify_fast(KOp& op)
+static void classify_fast(KOp& op, int frame_w)
 {
     op.fast_class = FC_NONE;
     op.csx = op.csy = 0;
-    if (op.kind != KOP_DRAW_PLANES || !(op.flags & KF_UNIT_SCALE) || op.blend_mode != 0 || (op.flags & KF_ADDITIVE))
+    if (op.kind == KOP_DRAW_SURFACE) {
+        /* a temporary composited over the frame (image_mixer.cpp:207-225): no loads, so the only requirement is that
+           lanes (4 pixels) are wholly inside or outside the box; pixels past the right frame edge are never stored */
+        if ((op.x0 & 3) == 0 && ((op.x1 & 3) == 0 || op.x1 == frame_w))
+            op.fast_class = FC_SURFACE;
         return;
-    if (op.dst != KS_RGBA0 && op.dst != KS_KEY0 && op.dst != KS_KEY1)
-        return; /* dst is bound later; re-checked in plan_frame */
+    }
+    /* item draws always carry blend mode 0 (the layer's mode is applied by its composite); checked anyway */
+    if (op.kind != KOP_DRAW_PLANES || !(op.flags & KF_UNIT_SCALE) || op.blend_mode != 0)
+        return;
     const KPlane& p0 = op.planes[0];
     if ((p0.w & 3) != 0)
         return; /* rows must keep 4-texel groups aligned */
@@ -527,14 +533,14 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
                         "frame needs more than 2 live RGBA temporaries or 2 live key textures at once");
         if (surfaces[d.target].channels == 1 && d.source_surface >= 0)
             return fail(CGHIP_ERR_INVALID, "surface-to-key draws do not exist in the reference renderer");
-        classify_fast(op); /* dst is known now */
+        classify_fast(op, fmt->width); /* dst is known now */
         classify_sampling(op);
         out->ops.push_back(op);
         if (d.source_surface < 0)
             for (int n = 0; n < d.nplanes; ++n)
                 out->planes.push_back(const_cast<cghip_plane*>(d.planes[n]));
     }
-    out->fast = !out->full;
+    out->fast = true; /* with out->full: the variant of the fast kernel that also holds the two RGBA temporaries */
     for (const KOp& o : out->ops)
         if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
             out->fast = false;

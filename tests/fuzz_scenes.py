@@ -105,9 +105,10 @@ def fuzz_scene(seed, bits=8):
     return S.scene("fuzz_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, square=square, field_mode=field_mode)
 
 
-def fuzz_fast_scene(seed, bits=8):
+def fuzz_fast_scene(seed, bits=8, full=False):
     """Random stacks the 4-pixels-per-lane kernel accepts: unit-scale layers of the frame's size (optionally cropped
-    or clipped on 4-pixel boundaries), normal blend, keys, every adjustment."""
+    or clipped on 4-pixel boundaries), keys, every adjustment; full=True adds blend-mode layers and MIX pairs, which
+    need the kernel variant with the layer / mix temporaries."""
     rng = random.Random(7000003 * seed + bits)
     W, H = rng.choice([(96, 64), (128, 36), (260, 50), (516, 22), (64, 90)])
     ops = []
@@ -146,5 +147,18 @@ def fuzz_fast_scene(seed, bits=8):
             t["invert"] = 1
         if r() < 0.25:
             t["is_key"] = 1
+        elif full and r() < 0.35:  # the layer goes through a layer temporary and is composited with a blend mode
+            t["blend_mode"] = rng.choice(S.BLEND_NAMES)
+        if full and not t.get("is_key") and r() < 0.25:  # MIX transition: two is_mix items in one layer
+            d = round(rng.random(), 2)
+            other = S.frame("bgra", [(W, H, 4, "premul", s + 50 + i)], bits)
+            lt = {k: v for k, v in t.items() if k in ("blend_mode", "opacity")}
+            lt["layer_depth"] = 1
+            it = {k: v for k, v in t.items() if k not in ("blend_mode", "opacity")}
+            ops.append([("push", lt),
+                        ("push", dict(it, is_mix=1, opacity=1.0 - d)), ("visit", src), ("pop",),
+                        ("push", dict(is_mix=1, opacity=d)), ("visit", other), ("pop",),
+                        ("pop",)])
+            continue
         ops.append(S.layer(src, **t))
     return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))

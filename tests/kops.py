@@ -49,4 +49,9 @@ def plan(fmt, surfaces, draws):
     rc = L.cghip_debug_plan(C.byref(fmt), sa, len(surfaces), da, len(draws), out, 512, C.byref(n), C.byref(full))
     if rc != 0:
         raise A.CGHIPError(rc, L.cghip_last_error().decode())
+    global last_plan_fast
+    last_plan_fast = bool(full.value & 2)  # every op qualifies for cghip_composite_fast
     return [out[i] for i in range(n.value)], bool(full.value & 1)
+
+
+last_plan_fast = False

@@ -72,8 +72,9 @@ def test_hip_matches_oracle_on_random_scenes(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("full", [False, True], ids=["normal_blend", "with_temporaries"])
 @pytest.mark.parametrize("bits", [8, 16])
-def test_fast_kernel_on_random_unit_scale_stacks(bits):
+def test_fast_kernel_on_random_unit_scale_stacks(bits, full):
     """Random stacks of the class cghip_composite_fast runs: it must equal the general kernel bit for bit at both
     depths (same texel placement, same arithmetic), and the oracle bit for bit at 8 bits."""
     import server_amd as A
@@ -83,7 +84,7 @@ def test_fast_kernel_on_random_unit_scale_stacks(bits):
     ran_fast = 0
     try:
         for seed in range(300):
-            sc = fuzz_fast_scene(seed, bits)
+            sc = fuzz_fast_scene(seed, bits, full)
             cache = {}
             fast = S.run_product(sc, mixer=m, planes_cache=cache)
             L.cghip_debug_force_general_kernel(1)

@@ -260,3 +260,18 @@ def test_many_key_layers_do_not_exhaust_surface_slots():
     assert len(surfaces) == 41 and not full
     assert sum(1 for o in kops if o.kind != K.KOP_CLEAR) == 80
     assert all(o.dst in (0, 3, 4) for o in kops)
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_fast_class_fuzz_scenes_are_planned_for_the_fast_kernel(full):
+    """The GPU fuzz of cghip_composite_fast (tests/test_fuzz.py) only means something if the planner really sends
+    those scenes there: every one of them must come out with the 'fast' bit, and the ones with blend-mode layers or
+    MIX pairs with 'full' as well."""
+    from fuzz_scenes import fuzz_fast_scene
+    n_full = 0
+    for seed in range(100):
+        sc = fuzz_fast_scene(seed, 8, full)
+        _d, _s, ops, is_full = product_plan(sc)
+        assert K.last_plan_fast or not ops, (seed, [(o.kind, o.fast_class) for o in ops])
+        n_full += int(is_full)
+    assert (n_full > 30) if full else (n_full == 0)
