@@ -16,11 +16,22 @@ extern "C" {
 int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces, const cghip_draw* draws,
                      int ndraws, void* kops_out, int capacity, int* nops, int* full);
 int cghip_debug_kop_size(void);
+/* In *full above: bit 0 = the frame uses RGBA temporaries, bit 1 = every draw is of the 4-pixels-per-lane class,
+ * bits 8.. = number of kernel launches (segments) the frame is cut into.
+ * The launches of a planned frame, 10 ints each: first op, op count, fast, full, load mask, store mask, and the pixel
+ * box gx0, gy0, gx1, gy1 the launch covers. Returns the number of launches (or an error < 0). */
+int cghip_debug_plan_segments(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces,
+                              const cghip_draw* draws, int ndraws, int* out, int capacity);
+/* At most n launches per frame (1 = never cut a frame; default 8). */
+void cghip_debug_max_segments(int n);
+/* Scales the planner's estimate of what a cut costs (default 1.0). 0 cuts wherever the kernel class changes, which
+ * is how the tests get small frames cut at all. */
+void cghip_debug_cut_cost_scale(double scale);
 /* A plane descriptor with no device memory behind it, for planner tests. Release with cghip_plane_release. */
 int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_plane** out);
 
-/* Forces the general one-pixel-per-lane kernel even for frames the 4-pixels-per-lane kernel could run, so
- * tests can compare the two. */
+/* Plans every frame as one launch of the general one-pixel-per-lane kernel, so tests can compare it with the
+ * 4-pixels-per-lane kernel and with frames cut into several launches. */
 void cghip_debug_force_general_kernel(int on);
 /* Launches the 4-pixels-per-lane kernel with this much unused dynamic LDS, which caps the workgroups resident on a
  * CU (160 KB each): occupancy experiments only (tests/gpu_occupancy.py). 0 = off. */

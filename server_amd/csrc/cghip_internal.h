@@ -42,7 +42,7 @@ struct cghip_device {
     std::mutex  mu;
     cghip::pool device_pool; /* hipMalloc'd blocks: planes, frame outputs, op lists */
     cghip::pool pinned_pool; /* hipHostMalloc'd blocks */
-    std::atomic<int64_t> planes_live{0}, tickets_live{0}, frames_rendered{0}, mixers{0};
+    std::atomic<int64_t> planes_live{0}, tickets_live{0}, frames_rendered{0}, kernel_launches{0}, mixers{0};
     std::atomic<int64_t> peer_copies{0}, peer_copy_bytes{0}; /* routed planes copied INTO this device */
     std::atomic<int64_t> uploads{0}, upload_bytes{0};        /* host-to-device plane uploads */
 
@@ -87,15 +87,28 @@ struct cghip_ticket {
     size_t                    ops_bytes = 0;
     hipEvent_t                ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
     int                       launches = 0;
+    void*                     spill[4] = {nullptr, nullptr, nullptr, nullptr}; /* RGBA1, RGBA2, KEY0, KEY1 between launches */
+    size_t                    spill_bytes[4] = {0, 0, 0, 0};
     std::vector<cghip_plane*> planes; /* retained until the frame is done */
 };
 
 namespace cghip {
 
+/* One kernel launch of a frame: a run of consecutive ops that one kernel class executes (cghip_plan.cpp). */
+struct segment {
+    int      first = 0, count = 0; /* ops[first, first + count) */
+    bool     fast = false;         /* cghip_composite_fast, else cghip_composite */
+    bool     full = false;         /* touches RGBA1 / RGBA2 */
+    uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
+    int      gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0; /* pixel box the launch covers */
+};
+
 struct frame_plan {
     std::vector<KOp> ops;
+    std::vector<segment> segments; /* never empty: an empty scene is one launch that stores the zero frame */
+    uint32_t         spill_mask = 0; /* KSurf bits (RGBA1..KEY1) that need a buffer in HBM between launches */
     bool             full = false; /* needs the RGBA1/RGBA2 register surfaces */
-    bool             fast = false; /* every draw qualifies for cghip_composite_fast */
+    bool             fast = false; /* every draw qualifies for cghip_composite_fast (then there is one segment) */
     std::vector<cghip_plane*> planes; /* every plane referenced by an emitted op */
 };
 
@@ -106,6 +119,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
 } // namespace cghip
 
 extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
-                                             int field_mode, int full, int fast, hipStream_t stream);
+                                             int field_mode, int full, int fast, const KSpill* sp, int gw, int gh,
+                                             hipStream_t stream);
 
 #endif

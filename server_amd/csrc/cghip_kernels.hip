@@ -772,23 +772,66 @@ DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
     return true;
 }
 
+/* ---- surfaces handed from one launch of a frame to the next (KSpill): UNORM codes <-> register values ---- */
+template <int BITS>
+DEV f4 load_px(const void* buf, size_t idx)
+{
+    if (BITS == 8) {
+        const uint32_t v  = ((const uint32_t*)buf)[idx];
+        const float    sc = 1.0f / 255.0f; /* == what quantize<8>() leaves in the register for code k */
+        return f4{(float)(v & 0xff) * sc, (float)((v >> 8) & 0xff) * sc, (float)((v >> 16) & 0xff) * sc, (float)(v >> 24) * sc};
+    }
+    const uint2 v  = ((const uint2*)buf)[idx];
+    const float sc = 1.0f / 65535.0f;
+    return f4{(float)(v.x & 0xffff) * sc, (float)(v.x >> 16) * sc, (float)(v.y & 0xffff) * sc, (float)(v.y >> 16) * sc};
+}
+template <int BITS>
+DEV void store_px(void* buf, size_t idx, f4 s)
+{
+    if (BITS == 8)
+        ((uint32_t*)buf)[idx] = to_code<8>(s.x) | (to_code<8>(s.y) << 8) | (to_code<8>(s.z) << 16) | (to_code<8>(s.w) << 24);
+    else
+        ((uint2*)buf)[idx] = uint2{to_code<16>(s.x) | (to_code<16>(s.y) << 16), to_code<16>(s.z) | (to_code<16>(s.w) << 16)};
+}
+template <int BITS>
+DEV float load_key(const void* buf, size_t idx)
+{
+    return BITS == 8 ? (float)((const uint8_t*)buf)[idx] * (1.0f / 255.0f) : (float)((const uint16_t*)buf)[idx] * (1.0f / 65535.0f);
+}
+template <int BITS>
+DEV void store_key(void* buf, size_t idx, float k)
+{
+    if (BITS == 8)
+        ((uint8_t*)buf)[idx] = (uint8_t)to_code<8>(k);
+    else
+        ((uint16_t*)buf)[idx] = (uint16_t)to_code<16>(k);
+}
+
 /* General compositor: one output pixel per lane (one wave = 64 consecutive pixels of a row, one
  * workgroup = 4 rows). FULL = false drops the two extra RGBA surfaces (layer / mix temporaries) from the
  * register file: the host picks it when the frame has only normal-blend, non-mix layers. Surfaces are
  * plain scalars selected by value, never arrays, so they stay in VGPRs. */
 template <int BITS, bool FULL>
-__global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
-                                                       int W, int H, int field_mode)
+__global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ ops, int nops, void* out, int W, int H,
+                                                       int field_mode, KSpill sp)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int y    = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave); /* wave-uniform: keep it scalar */
+    const int y    = __builtin_amdgcn_readfirstlane(sp.gy0 + blockIdx.y * 4 + wave); /* wave-uniform: keep it scalar */
     if (y >= H)
         return;
-    const int x = blockIdx.x * 64 + lane;
+    const int x = sp.gx0 + blockIdx.x * 64 + lane;
 
     f4    s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     float k0 = 0.0f, k1 = 0.0f;
+    if (sp.load_mask != 0 && x < W) { /* surfaces an earlier launch of this frame left in HBM */
+        const size_t idx = (size_t)y * W + x;
+        if (sp.load_mask & (1u << KS_RGBA0)) s0 = load_px<BITS>(out, idx);
+        if (FULL && (sp.load_mask & (1u << KS_RGBA1))) s1 = load_px<BITS>(sp.rgba1, idx);
+        if (FULL && (sp.load_mask & (1u << KS_RGBA2))) s2 = load_px<BITS>(sp.rgba2, idx);
+        if (sp.load_mask & (1u << KS_KEY0)) k0 = load_key<BITS>(sp.key0, idx);
+        if (sp.load_mask & (1u << KS_KEY1)) k1 = load_key<BITS>(sp.key1, idx);
+    }
 
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
@@ -851,13 +894,12 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
     /* frame store: memory order B,G,R,A = internal x,y,z,w (texture.cpp:100-105 reads back GL_BGRA) */
     if (x >= W)
         return;
-    if (BITS == 8) {
-        ((uint32_t*)out)[(size_t)y * W + x] =
-            to_code<8>(s0.x) | (to_code<8>(s0.y) << 8) | (to_code<8>(s0.z) << 16) | (to_code<8>(s0.w) << 24);
-    } else {
-        ((uint2*)out)[(size_t)y * W + x] = uint2{to_code<16>(s0.x) | (to_code<16>(s0.y) << 16),
-                                                 to_code<16>(s0.z) | (to_code<16>(s0.w) << 16)};
-    }
+    const size_t idx = (size_t)y * W + x;
+    if (sp.store_mask & (1u << KS_RGBA0)) store_px<BITS>(out, idx, s0);
+    if (FULL && (sp.store_mask & (1u << KS_RGBA1))) store_px<BITS>(sp.rgba1, idx, s1);
+    if (FULL && (sp.store_mask & (1u << KS_RGBA2))) store_px<BITS>(sp.rgba2, idx, s2);
+    if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0, idx, k0);
+    if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1, idx, k1);
 }
 
 /* Adjustment parameters copied into VGPRs once per op, for the 4-pixels-per-lane kernel: a VALU instruction with an
@@ -1220,8 +1262,8 @@ DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. Four waves per SIMD fit, which is enough here. */
 template <int BITS, bool FULL>
-__global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* __restrict__ out,
-                                                            int W, int H, int field_mode)
+__global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* out, int W, int H,
+                                                            int field_mode, KSpill sp)
 {
     constexpr int P    = 4;
     const int     lane = threadIdx.x & 63;
@@ -1238,6 +1280,19 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         S[i] = S1[i] = S2[i] = f4{0, 0, 0, 0};
         K0[i] = K1[i] = 0.0f;
     });
+    if (sp.load_mask != 0) { /* surfaces an earlier launch of this frame left in HBM (always the full grid here) */
+        static_for<0, P>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (px0 + i < W) {
+                const size_t idx = (size_t)y * W + px0 + i;
+                if (sp.load_mask & (1u << KS_RGBA0)) S[i] = load_px<BITS>(out, idx);
+                if (FULL && (sp.load_mask & (1u << KS_RGBA1))) S1[i] = load_px<BITS>(sp.rgba1, idx);
+                if (FULL && (sp.load_mask & (1u << KS_RGBA2))) S2[i] = load_px<BITS>(sp.rgba2, idx);
+                if (sp.load_mask & (1u << KS_KEY0)) K0[i] = load_key<BITS>(sp.key0, idx);
+                if (sp.load_mask & (1u << KS_KEY1)) K1[i] = load_key<BITS>(sp.key1, idx);
+            }
+        });
+    }
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
     for (int n = 0; n < nops && row_live; ++n) {
@@ -1336,6 +1391,20 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
 
     if (px0 >= W)
         return;
+    if (sp.store_mask & ~(1u << KS_RGBA0)) { /* surfaces a later launch of this frame needs */
+        static_for<0, P>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (px0 + i < W) {
+                const size_t idx = (size_t)y * W + px0 + i;
+                if (FULL && (sp.store_mask & (1u << KS_RGBA1))) store_px<BITS>(sp.rgba1, idx, S1[i]);
+                if (FULL && (sp.store_mask & (1u << KS_RGBA2))) store_px<BITS>(sp.rgba2, idx, S2[i]);
+                if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0, idx, K0[i]);
+                if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1, idx, K1[i]);
+            }
+        });
+    }
+    if (!(sp.store_mask & (1u << KS_RGBA0)))
+        return;
     if (BITS == 8) {
         uint32_t v[P];
         static_for<0, P>([&](auto I) {
@@ -1374,43 +1443,48 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
 
 /* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
 
-static int g_force_general = 0;
 static int g_pad_lds       = 0;
 static unsigned g_fast_rows = 4;
 extern "C" void cghip_debug_fast_rows(int rows) { g_fast_rows = rows >= 1 && rows <= 4 ? (unsigned)rows : 4u; }
-extern "C" void cghip_debug_force_general_kernel(int on) { g_force_general = on; }
 /* occupancy experiments: dynamic LDS nobody touches, to cap the workgroups resident on a CU (160 KB per CU) */
 extern "C" void cghip_debug_pad_lds(int bytes) { g_pad_lds = bytes; }
 
+/* One launch of a frame (cghip_plan.cpp: segment). sp->gx0, gy0 and gw, gh: the pixel box the grid covers. */
 extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
-                                             int field_mode, int full, int fast, hipStream_t stream)
+                                             int field_mode, int full, int fast, const KSpill* sp, int gw, int gh,
+                                             hipStream_t stream)
 {
-    dim3 block(256);
-    if (fast && !g_force_general) {
+    if (gw <= 0 || gh <= 0 || sp->gx0 < 0 || sp->gy0 < 0 || sp->gx0 + gw > W || sp->gy0 + gh > H)
+        return hipErrorInvalidValue;
+    const KSpill s = *sp;
+    dim3         block(256);
+    if (fast) {
+        if (s.gx0 != 0 || s.gy0 != 0)
+            return hipErrorInvalidValue; /* the 4-pixels-per-lane kernel always covers the frame */
         const unsigned rows = g_fast_rows; /* rows (= waves) per workgroup */
         block = dim3(64 * rows);
-        dim3 grid((unsigned)((W + 255) / 256), (unsigned)((H + rows - 1) / rows));
+        dim3 grid((unsigned)((gw + 255) / 256), (unsigned)((gh + rows - 1) / rows));
         if (bits == 8 && !full)
-            hipLaunchKernelGGL((cghip_composite_fast<8, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<8, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (bits == 8)
-            hipLaunchKernelGGL((cghip_composite_fast<8, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<8, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!full)
-            hipLaunchKernelGGL((cghip_composite_fast<16, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<16, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else
-            hipLaunchKernelGGL((cghip_composite_fast<16, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite_fast<16, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         return hipGetLastError();
     }
-    dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4));
+    dim3 grid((unsigned)((gw + 63) / 64), (unsigned)((gh + 3) / 4));
     if (bits == 8) {
         if (full)
-            hipLaunchKernelGGL((cghip_composite<8, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite<8, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else
-            hipLaunchKernelGGL((cghip_composite<8, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite<8, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
     } else {
         if (full)
-            hipLaunchKernelGGL((cghip_composite<16, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite<16, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else
-            hipLaunchKernelGGL((cghip_composite<16, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode);
+            hipLaunchKernelGGL((cghip_composite<16, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
     }
     return hipGetLastError();
 }

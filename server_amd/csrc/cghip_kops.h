@@ -58,6 +58,22 @@ enum KSurf : int32_t {
     KS_COUNT = 5
 };
 
+/* A frame whose draws fall into different kernel classes is composited by several launches, one per run of draws
+ * of one class (cghip_plan.cpp: segments). The register surfaces that are live across a launch boundary travel
+ * through HBM in the frame's own format: RGBA0 in the frame buffer itself, the others in these buffers. Stored values
+ * are UNORM codes, which is exactly what the registers hold (every draw ends in a UNORM store), so the hand-over is
+ * lossless. Bit s of the masks = KSurf s. gx0, gy0: pixel origin of the launch grid (a launch may cover only the box
+ * its draws can touch). */
+struct KSpill {
+    void*    rgba1;
+    void*    rgba2;
+    void*    key0;
+    void*    key1;
+    uint32_t load_mask;  /* surfaces to read before the first op */
+    uint32_t store_mask; /* surfaces to write after the last op */
+    int32_t  gx0, gy0;
+};
+
 struct KPlane {
     const void* ptr;
     int32_t     w, h;

@@ -437,6 +437,135 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
     return 1;
 }
 
+/* ---- segments: which kernel runs which run of ops --------------------------------------------------------------
+ * The 4-pixels-per-lane kernel is 3 to 6 times as fast per draw as the general one but takes only unit-scale
+ * draws. A frame with one scaled box over a stack of full-screen layers should not pay the general price for the
+ * whole stack, so the op list is cut into runs and every run gets its own launch; surfaces that are live across a
+ * cut travel through HBM (KSpill). A cut costs a round trip of the frame (and a launch), which is worth about half a
+ * full-screen draw of the general kernel: a two-state shortest path over the op list decides where cutting pays. */
+static int g_force_general = 0;
+static int g_max_segments  = 8;
+static double g_cut_scale  = 1.0;
+
+static uint32_t surf_bit(int s) { return s >= 0 && s < KS_COUNT ? 1u << s : 0u; }
+static uint32_t refs_of(const KOp& o) /* surfaces an op reads or writes */
+{
+    if (o.kind == KOP_CLEAR)
+        return surf_bit(o.dst);
+    return surf_bit(o.dst) | surf_bit(o.local_key) | surf_bit(o.layer_key) |
+           (o.kind == KOP_DRAW_SURFACE ? surf_bit(o.src_surface) : 0u);
+}
+
+static void split_into_segments(const cghip_format& fmt, frame_plan* out)
+{
+    const std::vector<KOp>& ops = out->ops;
+    const int               n   = (int)ops.size();
+    const int               W = fmt.width, H = fmt.height;
+    out->segments.clear();
+    out->spill_mask = 0;
+
+    /* 1. kernel class per op: min-cost path, states 0 = general, 1 = fast. Costs in picoseconds, measured with
+       tests/gpu_segments_probe.py: per pixel of a draw's box, a 16-bit / 8-bit planar layer
+       takes about 9 / 5 ps in the general kernel and 1.6 / 1.9 ps in the fast one; a cut costs a round trip of the
+       frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (about 4 us). */
+    std::vector<uint8_t> cls((size_t)n, out->fast && !g_force_general ? 1 : 0);
+    if (n > 0 && !out->fast && !g_force_general && g_max_segments > 1) {
+        const double per_px[2] = {fmt.bits == 16 ? 9.0 : 5.0, fmt.bits == 16 ? 1.6 : 1.9};
+        const double cut       = ((double)W * H * (fmt.bits == 16 ? 3.1 : 1.6) + 4e6) * g_cut_scale;
+        const double inf       = 1e300;
+        std::vector<double>  cost((size_t)(n + 1) * 2, inf);
+        std::vector<uint8_t> from((size_t)(n + 1) * 2, 0);
+        cost[0] = cost[1] = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const KOp&   o    = ops[(size_t)i];
+            const bool   clr  = o.kind == KOP_CLEAR;
+            const double area = clr ? 0.0 : (double)std::max(0, o.x1 - o.x0) * std::max(0, o.y1 - o.y0);
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && !clr && o.fast_class == FC_NONE)
+                    continue;
+                for (int j = 0; j < 2; ++j) {
+                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut : 0.0) + area * per_px[k];
+                    if (c < cost[(size_t)(i + 1) * 2 + k]) {
+                        cost[(size_t)(i + 1) * 2 + k] = c;
+                        from[(size_t)(i + 1) * 2 + k] = (uint8_t)j;
+                    }
+                }
+            }
+        }
+        int k = cost[(size_t)n * 2 + 1] < cost[(size_t)n * 2] ? 1 : 0;
+        for (int i = n; i > 0; --i) {
+            cls[(size_t)i - 1] = (uint8_t)k;
+            k                  = from[(size_t)i * 2 + k];
+        }
+        int cuts = 0;
+        for (int i = 1; i < n; ++i)
+            cuts += cls[(size_t)i] != cls[(size_t)i - 1];
+        if (cuts + 1 > g_max_segments)
+            std::fill(cls.begin(), cls.end(), (uint8_t)0);
+    }
+
+    /* 2. runs of one class */
+    for (int i = 0; i < n;) {
+        segment sg;
+        sg.first = i;
+        sg.fast  = cls[(size_t)i] != 0;
+        while (i < n && (cls[(size_t)i] != 0) == sg.fast)
+            ++i;
+        sg.count = i - sg.first;
+        out->segments.push_back(sg);
+    }
+    if (out->segments.empty()) {
+        segment sg;
+        sg.fast = !g_force_general; /* empty scene: the zero frame (image_mixer.cpp:89-92) */
+        out->segments.push_back(sg);
+    }
+
+    /* 3. which surfaces cross the cuts. in_mem: the HBM copy is the current value; a surface whose last write in a
+       segment is a CLEAR is zero, and zero is what a launch's registers start from, so it needs no copy. */
+    const size_t nseg   = out->segments.size();
+    uint32_t     in_mem = 0;
+    for (size_t si = 0; si < nseg; ++si) {
+        segment& sg      = out->segments[si];
+        uint32_t touched = 0, written = 0, zero = 0, later = surf_bit(KS_RGBA0);
+        for (int i = sg.first; i < sg.first + sg.count; ++i) {
+            const KOp& o = ops[(size_t)i];
+            touched |= refs_of(o);
+            written |= surf_bit(o.dst);
+            if (o.kind == KOP_CLEAR)
+                zero |= surf_bit(o.dst);
+            else
+                zero &= ~surf_bit(o.dst);
+        }
+        for (int i = sg.first + sg.count; i < n; ++i)
+            if (ops[(size_t)i].kind != KOP_CLEAR)
+                later |= refs_of(ops[(size_t)i]);
+        sg.full       = (touched & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0;
+        sg.load_mask  = touched & in_mem;
+        sg.store_mask = written & ~zero & later;
+        if (si == 0)
+            sg.store_mask |= surf_bit(KS_RGBA0); /* the first launch defines every pixel of the frame */
+        in_mem = (in_mem & ~written) | sg.store_mask;
+        out->spill_mask |= (sg.load_mask | sg.store_mask) & ~surf_bit(KS_RGBA0);
+
+        /* 4. a general launch that hands nothing but the frame itself onwards only has to cover its draws */
+        sg.gx0 = sg.gy0 = 0, sg.gx1 = W, sg.gy1 = H;
+        if (si > 0 && !sg.fast && (sg.store_mask & ~surf_bit(KS_RGBA0)) == 0) {
+            int bx0 = W, by0 = H, bx1 = 0, by1 = 0;
+            for (int i = sg.first; i < sg.first + sg.count; ++i) {
+                const KOp& o = ops[(size_t)i];
+                if (o.kind == KOP_CLEAR)
+                    continue;
+                bx0 = std::min(bx0, o.x0), by0 = std::min(by0, o.y0);
+                bx1 = std::max(bx1, o.x1), by1 = std::max(by1, o.y1);
+            }
+            bx0 = std::max(bx0, 0) & ~63, by0 = std::max(by0, 0) & ~3; /* whole waves, whole workgroups */
+            bx1 = std::min(bx1, W), by1 = std::min(by1, H);
+            if (bx0 < bx1 && by0 < by1)
+                sg.gx0 = bx0, sg.gy0 = by0, sg.gx1 = bx1, sg.gy1 = by1;
+        }
+    }
+}
+
 int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces, const cghip_draw* draws,
                int ndraws, frame_plan* out)
 {
@@ -544,6 +673,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
     for (const KOp& o : out->ops)
         if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
             out->fast = false;
+    split_into_segments(*fmt, out);
     return CGHIP_OK;
 }
 
@@ -561,7 +691,7 @@ extern "C" int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* su
     if (nops)
         *nops = (int)plan.ops.size();
     if (full)
-        *full = (plan.full ? 1 : 0) | (plan.fast ? 2 : 0);
+        *full = (plan.full ? 1 : 0) | (plan.fast ? 2 : 0) | ((int)plan.segments.size() << 8);
     if (kops_out) {
         const int n = std::min(capacity, (int)plan.ops.size());
         std::memcpy(kops_out, plan.ops.data(), (size_t)n * sizeof(KOp));
@@ -570,3 +700,29 @@ extern "C" int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* su
 }
 
 extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }
+
+/* test hooks: one launch of the general kernel per frame / at most n launches per frame (1 = never cut) */
+extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_general = on; }
+extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }
+/* scales what the planner thinks a cut costs: 0 cuts at every change of class (tests: small frames never cut otherwise) */
+extern "C" void cghip_debug_cut_cost_scale(double scale) { cghip::g_cut_scale = scale >= 0.0 ? scale : 1.0; }
+
+/* Introspection: the launches of a planned frame, 10 ints each: first, count, fast, full, load_mask, store_mask,
+ * gx0, gy0, gx1, gy1. Returns the number of segments. */
+extern "C" int cghip_debug_plan_segments(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces,
+                                         const cghip_draw* draws, int ndraws, int* out, int capacity)
+{
+    cghip::frame_plan plan;
+    const int         rc = cghip::plan_frame(fmt, surfaces, nsurfaces, draws, ndraws, &plan);
+    if (rc != CGHIP_OK)
+        return rc;
+    int k = 0;
+    for (const cghip::segment& sg : plan.segments) {
+        if (k >= capacity)
+            break;
+        const int v[10] = {sg.first, sg.count, sg.fast, sg.full, (int)sg.load_mask, (int)sg.store_mask, sg.gx0, sg.gy0, sg.gx1, sg.gy1};
+        std::memcpy(out + (size_t)k * 10, v, sizeof v);
+        ++k;
+    }
+    return (int)plan.segments.size();
+}

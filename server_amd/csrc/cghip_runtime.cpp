@@ -191,13 +191,14 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
                      "{\"gpu\":%d,\"name\":\"%s\",\"hbm_total_bytes\":%zu,\"hbm_free_bytes\":%zu,"
                      "\"device_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"pinned_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
-                     "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld,"
+                     "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld,\"kernel_launches\":%lld,"
                      "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld,\"uploads\":%lld,\"upload_bytes\":%lld}",
                      dev->gpu, dev->name.c_str(), total_b, free_b, dev->device_pool.count_total,
                      dev->device_pool.bytes_total, dev->device_pool.bytes_free, dev->pinned_pool.count_total,
                      dev->pinned_pool.bytes_total, dev->pinned_pool.bytes_free, (long long)dev->planes_live.load(),
                      (long long)dev->tickets_live.load(), (long long)dev->mixers.load(),
-                     (long long)dev->frames_rendered.load(), (long long)dev->peer_copies.load(),
+                     (long long)dev->frames_rendered.load(), (long long)dev->kernel_launches.load(),
+                     (long long)dev->peer_copies.load(),
                      (long long)dev->peer_copy_bytes.load(), (long long)dev->uploads.load(),
                      (long long)dev->upload_bytes.load());
     if (n < 0 || (size_t)n >= capacity)
@@ -446,6 +447,8 @@ static void ticket_free(cghip_ticket* t)
     if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
     dev->dev_free(t->d_out, t->out_bytes);
     dev->dev_free(t->d_ops, t->ops_bytes);
+    for (int i = 0; i < 4; ++i)
+        dev->dev_free(t->spill[i], t->spill_bytes[i]);
     dev->pinned_free(t->h_ops, t->ops_bytes);
     dev->pinned_free(t->h_out, t->out_bytes);
     for (cghip_plane* p : t->planes)
@@ -509,10 +512,24 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
         T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, t->stream));
     }
     T_HIP(hipEventRecord(t->ev_start, t->stream));
-    /* empty scene: the kernel with zero ops writes the all-zero frame (image_mixer.cpp:89-92) */
-    T_HIP(cghip_launch_composite((const KOp*)t->d_ops, (int)plan.ops.size(), t->d_out, format->width, format->height,
-                                 format->bits, format->field_mode, plan.full ? 1 : 0, plan.fast ? 1 : 0, t->stream));
-    t->launches = 1;
+    /* one launch per segment of the plan, in order on the mixer's stream; surfaces that are live across a cut travel
+       through the frame buffer (RGBA0) and the ticket's spill buffers. An empty scene is one launch with zero ops
+       that writes the all-zero frame (image_mixer.cpp:89-92). */
+    for (int i = 0; i < 4; ++i)
+        if (plan.spill_mask & (1u << (KS_RGBA1 + i))) {
+            t->spill_bytes[i] = (size_t)format->width * format->height * (i < 2 ? 4 : 1) * (format->bits / 8);
+            T_TRY(dev->dev_alloc(t->spill_bytes[i], &t->spill[i]));
+        }
+    for (const segment& sg : plan.segments) {
+        KSpill sp;
+        sp.rgba1 = t->spill[0], sp.rgba2 = t->spill[1], sp.key0 = t->spill[2], sp.key1 = t->spill[3];
+        sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
+        sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
+        T_HIP(cghip_launch_composite((const KOp*)t->d_ops + sg.first, sg.count, t->d_out, format->width, format->height,
+                                     format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 : 0, &sp,
+                                     sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, t->stream));
+        t->launches++;
+    }
     T_HIP(hipEventRecord(t->ev_stop, t->stream));
     if (flags & CGHIP_RENDER_READBACK) {
         T_TRY(dev->pinned_alloc(t->out_bytes, &t->h_out));
@@ -532,6 +549,7 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
 #undef T_TRY
 #undef T_HIP
     dev->frames_rendered++;
+    dev->kernel_launches += t->launches;
     *out = t;
     return CGHIP_OK;
 }

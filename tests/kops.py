@@ -55,3 +55,29 @@ def plan(fmt, surfaces, draws):
 
 
 last_plan_fast = False
+
+
+SEG_FIELDS = ("first", "count", "fast", "full", "load_mask", "store_mask", "gx0", "gy0", "gx1", "gy1")
+
+
+def plan_segments(fmt, surfaces, draws):
+    """The kernel launches the planner cuts a frame into (no GPU): list of dicts with SEG_FIELDS."""
+    import server_amd as A
+    L = A.lib()
+    sa = (A.Surface * len(surfaces))(*[A.Surface(c, 0) for c in surfaces])
+    da = (A.Draw * max(1, len(draws)))(*draws)
+    out = (C.c_int * (10 * 64))()
+    n = L.cghip_debug_plan_segments(C.byref(fmt), sa, len(surfaces), da, len(draws), out, 64)
+    if n < 0:
+        raise A.CGHIPError(n, L.cghip_last_error().decode())
+    assert n <= 64
+    return [dict(zip(SEG_FIELDS, out[i * 10:(i + 1) * 10])) for i in range(n)]
+
+
+def set_cut_policy(cut_cost_scale=1.0, max_segments=8):
+    import server_amd as A
+    L = A.lib()
+    L.cghip_debug_cut_cost_scale.argtypes = [C.c_double]
+    L.cghip_debug_cut_cost_scale.restype = None
+    L.cghip_debug_cut_cost_scale(float(cut_cost_scale))
+    L.cghip_debug_max_segments(int(max_segments))

@@ -107,3 +107,39 @@ def test_fast_kernel_on_random_unit_scale_stacks(bits, full):
     finally:
         m.close()
     assert ran_fast == 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
+def test_frames_cut_into_several_launches_equal_one_launch(bits):
+    """Frames whose draws fall into both kernel classes are cut into runs, one launch each, with the live surfaces
+    handed over through HBM as UNORM codes (cghip_plan.cpp: split_into_segments). With the cut cost forced to zero the
+    small fuzz scenes are cut wherever the class changes; the result must equal the single general launch bit for
+    bit: same arithmetic per draw, and the hand-over is lossless because every draw ends in a UNORM store."""
+    import json
+    import kops as K
+    import server_amd as A
+    from fuzz_scenes import fuzz_scene, fuzz_fast_scene
+    m = A.Mixer(channel_id=5, gpu=0)
+    L = A.lib()
+    n_cut = 0
+    try:
+        for seed in range(400):
+            sc = fuzz_scene(seed, bits) if seed % 4 else fuzz_fast_scene(seed, bits, True)
+            cache = {}
+            L.cghip_debug_force_general_kernel(1)
+            try:
+                general = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_force_general_kernel(0)
+            before = m.device_info()["kernel_launches"]
+            K.set_cut_policy(cut_cost_scale=0.0, max_segments=64)
+            try:
+                cut = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                K.set_cut_policy()
+            n_cut += m.device_info()["kernel_launches"] - before > 1
+            assert np.array_equal(cut, general), (seed, S.diff_stats(cut, general))
+    finally:
+        m.close()
+    assert n_cut > 80, n_cut

@@ -148,6 +148,36 @@ def test_fast_kernel_equals_general_kernel(mixer):
         assert (so["max"] <= 1 and so["gt0"] <= 1e-4) if bits == 8 else (so["gt2"] <= 1e-4), so
 
 
+@pytest.mark.parametrize("bits", [8, 16])
+def test_mixed_frame_is_cut_into_launches_by_the_default_policy(mixer, bits):
+    """A 1080p rundown of full-screen layers around one scaled box and a keyed, scaled pair: the planner's own cost
+    model (no test hooks) cuts it into launches of the two kernels; the result equals the single general launch bit for
+    bit, and the oracle to the configs' bar."""
+    import server_amd as A
+    L = A.lib()
+    W, H = 1920, 1080
+    ops = [S.layer(S.ycbcr(W, H, "422", "video", 800 + i, bits=bits), opacity=0.9) for i in range(5)]
+    ops.append(S.layer(S.bgra(W // 2, H // 2, "premul", 810, bits=bits), fill_translation=[0.55, 0.5], fill_scale=[0.3, 0.3]))
+    ops += [S.layer(S.bgra(W, H, "premul", 820 + i, bits=bits), opacity=0.8) for i in range(5)]
+    ops.append(S.layer(S.bgra(W, H, "smooth", 830, bits=bits), is_key=1))  # key drawn by the fast kernel ...
+    ops.append(S.layer(S.bgra(W, H, "premul", 831, bits=bits), fill_scale=[0.999, 0.999], opacity=0.7))  # ... used by the general one
+    ops += [S.layer(S.ycbcr(W, H, "420", "video", 840 + i, bits=bits), opacity=0.6) for i in range(5)]
+    sc = S.scene("mixed", W, H, ops, bits=bits)
+    cache = {}
+    before = mixer.device_info()["kernel_launches"]
+    cut = S.run_product(sc, mixer=mixer, planes_cache=cache)
+    # fast, box, fast (+key), general (keyed fill), fast
+    assert mixer.device_info()["kernel_launches"] - before == 5
+    L.cghip_debug_force_general_kernel(1)
+    try:
+        general = S.run_product(sc, mixer=mixer, planes_cache=cache)
+    finally:
+        L.cghip_debug_force_general_kernel(0)
+    assert np.array_equal(cut, general), S.diff_stats(cut, general)
+    so = S.diff_stats(cut, S.run_oracle(sc, "cpu", cache))
+    assert so["max"] == 0 if bits == 8 else so["gt2"] <= 1e-3, so
+
+
 FULL = [("config1", lambda: S.config1()), ("config2", lambda: S.config2()), ("config4", lambda: S.config4()),
         ("config3_8bit", lambda: S.config3(bits=8)), ("config3_16bit", lambda: S.config3(bits=16))]
 

@@ -275,3 +275,124 @@ def test_fast_class_fuzz_scenes_are_planned_for_the_fast_kernel(full):
         assert K.last_plan_fast or not ops, (seed, [(o.kind, o.fast_class) for o in ops])
         n_full += int(is_full)
     assert (n_full > 30) if full else (n_full == 0)
+
+
+# ---------------------------------------------------------------- frames cut into several launches (segments)
+
+def check_segments(ops, segs, W, H):
+    """Replays the hand-over of the register surfaces between the launches of one frame with version numbers: every
+    op must see, in its launch's registers, the value a single launch would hold; the frame buffer must end up with
+    the last RGBA0."""
+    assert segs and segs[0]["first"] == 0 and sum(s["count"] for s in segs) == len(ops)
+    ZERO = 0
+    true = [ZERO] * 5   # value a single launch would hold
+    mem = [None] * 5    # value in HBM (None: never written)
+    version = 0
+    for si, sg in enumerate(segs):
+        assert sg["first"] == (segs[si - 1]["first"] + segs[si - 1]["count"] if si else 0)
+        assert si == 0 or sg["count"] > 0
+        boxed = (sg["gx0"], sg["gy0"], sg["gx1"], sg["gy1"]) != (0, 0, W, H)
+        if boxed:
+            assert si > 0 and not sg["fast"] and sg["store_mask"] & ~1 == 0
+            assert sg["gx0"] % 64 == 0 and sg["gy0"] % 4 == 0
+        if si == 0:
+            assert sg["store_mask"] & 1 and sg["load_mask"] == 0
+        regs = [ZERO] * 5
+        for s in range(5):
+            if sg["load_mask"] & (1 << s):
+                assert mem[s] is not None, (si, s, "loads a surface nobody stored")
+                regs[s] = mem[s]
+        for o in ops[sg["first"]:sg["first"] + sg["count"]]:
+            if o.kind == K.KOP_CLEAR:
+                regs[o.dst] = true[o.dst] = ZERO
+                continue
+            if not sg["full"]:
+                assert o.dst not in (1, 2) and o.kind != K.KOP_DRAW_SURFACE
+            if sg["fast"]:
+                assert o.fast_class != 0
+            if boxed:
+                assert sg["gx0"] <= o.x0 and o.x1 <= sg["gx1"] and sg["gy0"] <= o.y0 and o.y1 <= sg["gy1"]
+            reads = [o.dst, o.local_key, o.layer_key] + ([o.src_surface] if o.kind == K.KOP_DRAW_SURFACE else [])
+            for s in reads:
+                if s >= 0:
+                    assert regs[s] == true[s], (si, s, "stale surface")
+            version += 1
+            regs[o.dst] = true[o.dst] = version
+        for s in range(5):
+            if sg["store_mask"] & (1 << s):
+                # a boxed launch rewrites only its box of RGBA0; outside it the registers were loaded from mem
+                mem[s] = regs[s]
+    assert mem[0] == true[0]
+
+
+def mixed_scene(W, H, bits=8, n_before=6, n_after=6):
+    ops = [S.layer(S.bgra(W, H, "premul", 10 + i, bits=bits), opacity=0.9) for i in range(n_before)]
+    ops.append(S.layer(S.bgra(W // 2, H // 2, "premul", 40, bits=bits), fill_translation=[0.55, 0.5],
+                       fill_scale=[0.3, 0.3]))
+    ops += [S.layer(S.bgra(W, H, "premul", 60 + i, bits=bits), opacity=0.8) for i in range(n_after)]
+    return S.scene("mixed", W, H, ops, bits=bits)
+
+
+def plan_with_segments(sc):
+    m = A.Mixer(channel_id=1, gpu=-2)
+    try:
+        S.feed_product(m, sc, via_factory=False)
+        draws, surfaces = m.flatten(sc["width"], sc["height"], sc["square_width"], sc["square_height"], sc["bits"])
+        fmt = A.Format(sc["width"], sc["height"], sc["square_width"], sc["square_height"], sc["bits"], 0)
+        ops, _full = K.plan(fmt, surfaces, draws)
+        return ops, K.plan_segments(fmt, surfaces, draws)
+    finally:
+        m.close()
+
+
+def test_a_scaled_box_between_full_screen_layers_gets_its_own_small_launch():
+    W, H = 1920, 1080
+    ops, segs = plan_with_segments(mixed_scene(W, H))
+    assert [s["fast"] for s in segs] == [1, 0, 1]
+    check_segments(ops, segs, W, H)
+    box = segs[1]
+    assert box["load_mask"] == 1 and box["store_mask"] == 1
+    assert (box["gx1"] - box["gx0"]) * (box["gy1"] - box["gy0"]) < W * H // 4
+    assert segs[2]["load_mask"] == 1 and segs[2]["store_mask"] == 1
+    # one 8-bit fast layer on either side of a full-screen general draw does not pay for two cuts (measured:
+    # tests/gpu_segments_probe.py), the frame stays one general launch
+    sc = mixed_scene(W, H, n_before=1, n_after=1)
+    sc["ops"][3][1].update(fill_translation=[0.0, 0.0], fill_scale=[0.999, 0.999])
+    ops, segs = plan_with_segments(sc)
+    assert len(segs) == 1 and not segs[0]["fast"]
+    check_segments(ops, segs, W, H)
+    # small frames are launch-bound: never cut
+    ops, segs = plan_with_segments(mixed_scene(96, 64))
+    assert len(segs) == 1
+    try:
+        K.set_cut_policy(max_segments=1)
+        ops, segs = plan_with_segments(mixed_scene(W, H))
+        assert len(segs) == 1 and not segs[0]["fast"]
+    finally:
+        K.set_cut_policy()
+
+
+def test_empty_scene_is_one_launch_that_stores_the_frame():
+    fmt = A.Format(64, 64, 64, 64, 8, 0)
+    segs = K.plan_segments(fmt, [4], [])
+    assert len(segs) == 1 and segs[0]["count"] == 0 and segs[0]["store_mask"] == 1 and segs[0]["load_mask"] == 0
+    assert (segs[0]["gx1"], segs[0]["gy1"]) == (64, 64)
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_fuzz_scenes_cut_at_every_class_change_hand_surfaces_over_correctly(bits):
+    """With the cut cost forced to zero the planner cuts wherever the kernel class changes; the replay above checks
+    that keys and layer / mix temporaries that are live across a cut are stored and loaded, for 300 random scenes."""
+    from fuzz_scenes import fuzz_scene, fuzz_fast_scene
+    n_cut = n_spill = 0
+    try:
+        K.set_cut_policy(cut_cost_scale=0.0, max_segments=64)
+        for seed in range(300):
+            sc = fuzz_scene(seed, bits) if seed % 3 else fuzz_fast_scene(seed, bits, True)
+            ops, segs = plan_with_segments(sc)
+            check_segments(ops, segs, sc["width"], sc["height"])
+            n_cut += len(segs) > 1
+            n_spill += any((s["load_mask"] | s["store_mask"]) & ~1 for s in segs)
+    finally:
+        K.set_cut_policy()
+    assert n_cut > 60 and n_spill > 20, (n_cut, n_spill)
