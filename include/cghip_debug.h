@@ -33,6 +33,9 @@ int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_
 /* Plans every frame as one launch of the general one-pixel-per-lane kernel, so tests can compare it with the
  * 4-pixels-per-lane kernel and with frames cut into several launches. */
 void cghip_debug_force_general_kernel(int on);
+/* The general kernel samples the common plane layouts (KSampleClass) with straight-line bodies; on = every draw takes
+ * the generic per-format path instead, so tests can compare the two. */
+void cghip_debug_generic_sampling(int on);
 /* Launches the 4-pixels-per-lane kernel with this much unused dynamic LDS, which caps the workgroups resident on a
  * CU (160 KB each): occupancy experiments only (tests/gpu_occupancy.py). 0 = off. */
 void cghip_debug_pad_lds(int bytes);

@@ -717,6 +717,65 @@ DEV f4 source_color_class(const KOp& op, const HotG& h, float s, float t, int px
     return ycbcra_to_rgba(Y, Cb, Cr, A, h.flags & KF_IS_HD);
 }
 
+/* ---- the same for the two common 16-bit layouts: fp32 weights (sample16_float), straight-line ---- */
+struct TapsF {
+    uint32_t o00, o01, o10, o11;
+    float    wx, wy;
+};
+DEV TapsF make_taps_f(float u, float v, int w, int h, uint32_t texel_bytes)
+{
+    const float fx = __builtin_floorf(u), fy = __builtin_floorf(v);
+    int         x0 = (int)fx, y0 = (int)fy;
+    const int   x1 = iclamp(x0 + 1, 0, w - 1), y1 = iclamp(y0 + 1, 0, h - 1);
+    x0             = iclamp(x0, 0, w - 1);
+    y0             = iclamp(y0, 0, h - 1);
+    const uint32_t r0 = (uint32_t)y0 * (uint32_t)w, r1 = (uint32_t)y1 * (uint32_t)w;
+    return TapsF{(r0 + (uint32_t)x0) * texel_bytes, (r0 + (uint32_t)x1) * texel_bytes, (r1 + (uint32_t)x0) * texel_bytes,
+                 (r1 + (uint32_t)x1) * texel_bytes, u - fx, v - fy};
+}
+/* v0 + w*(v1 - v0), x first, then y; a zero weight leaves the first operand untouched, so no tap is conditional */
+DEV float bilerp_f(float a00, float a01, float a10, float a11, float wx, float wy)
+{
+    const float a = a00 + wx * (a01 - a00), c = a10 + wx * (a11 - a10);
+    return a + wy * (c - a);
+}
+DEV float tap1_16(uint64_t ptr, const TapsF t)
+{
+    const GB    b  = (GB)ptr;
+    const float sc = 1.0f / 65535.0f;
+    return bilerp_f((float)load_at<uint16_t>(b, t.o00) * sc, (float)load_at<uint16_t>(b, t.o01) * sc,
+                    (float)load_at<uint16_t>(b, t.o10) * sc, (float)load_at<uint16_t>(b, t.o11) * sc, t.wx, t.wy);
+}
+template <bool UNIT>
+DEV f4 source_color_class16(const KOp& op, const HotG& h, float s, float t, int px, int py)
+{
+    auto coord = [&](float v, float size, float size0, int p) -> float {
+        if (UNIT)
+            return ((float)p + 0.5f) * (size / size0) - 0.5f; /* sample_unit */
+        return v * size - 0.5f;                               /* sample_norm */
+    };
+    const float sc = 1.0f / 65535.0f;
+    if (h.sample_class == SC_PACKED16) {
+        const TapsF t0 = make_taps_f(coord(s, h.fw0, h.fw0, px), coord(t, h.fh0, h.fh0, py), h.w0, h.h0, 8u);
+        const GB    b  = (GB)h.ptr0;
+        const u32x2 a00 = load_at<u32x2>(b, t0.o00), a01 = load_at<u32x2>(b, t0.o01);
+        const u32x2 a10 = load_at<u32x2>(b, t0.o10), a11 = load_at<u32x2>(b, t0.o11);
+#define CH(v, k) ((float)((k) == 0 ? (v).x & 0xffff : (k) == 1 ? (v).x >> 16 : (k) == 2 ? (v).y & 0xffff : (v).y >> 16) * sc)
+#define LERP(k) bilerp_f(CH(a00, k), CH(a01, k), CH(a10, k), CH(a11, k), t0.wx, t0.wy)
+        const float m0 = LERP(0), m1 = LERP(1), m2 = LERP(2), m3 = LERP(3);
+#undef LERP
+#undef CH
+        return swizzle_format(h.pixel_format, f4{m2, m1, m0, m3}); /* gl_texel of a GL_BGRA upload */
+    }
+    const TapsF t0 = make_taps_f(coord(s, h.fw0, h.fw0, px), coord(t, h.fh0, h.fh0, py), h.w0, h.h0, 2u);
+    const TapsF t1 = make_taps_f(coord(s, h.fw1, h.fw0, px), coord(t, h.fh1, h.fh0, py), h.w1, h.h1, 2u);
+    const float Y = tap1_16(h.ptr0, t0), Cb = tap1_16(h.ptr1, t1), Cr = tap1_16(h.ptr2, t1);
+    float       A = 1.0f;
+    if (h.pixel_format == 6)
+        A = tap1_16(h.ptr3, t0);
+    return ycbcra_to_rgba(Y, Cb, Cr, A, h.flags & KF_IS_HD);
+}
+
 /* Source colour of a KOP_DRAW_PLANES at pixel (x,y); false when the pixel centre is outside the quad. */
 DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
 {
@@ -726,8 +785,9 @@ DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
        the exact texel keeps this kernel and cghip_composite_fast identical on the layers they share. */
     if (h.flags & KF_UNIT_SCALE) {
         const int px = x + h.unit_dx, py = y + h.unit_dy;
-        color = h.sample_class != SC_GENERIC ? source_color_class<true>(op, h, 0.0f, 0.0f, px, py)
-                                             : source_color_unit(op, px, py);
+        color = h.sample_class >= SC_PLANAR16  ? source_color_class16<true>(op, h, 0.0f, 0.0f, px, py)
+                : h.sample_class != SC_GENERIC ? source_color_class<true>(op, h, 0.0f, 0.0f, px, py)
+                                               : source_color_unit(op, px, py);
         return true;
     }
     const double dx = (double)x, dy = (double)y;
@@ -768,7 +828,9 @@ DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
             t /= q0;
         }
     }
-    color = h.sample_class != SC_GENERIC ? source_color_class<false>(op, h, s, t, 0, 0) : source_color_norm(op, s, t);
+    color = h.sample_class >= SC_PLANAR16  ? source_color_class16<false>(op, h, s, t, 0, 0)
+            : h.sample_class != SC_GENERIC ? source_color_class<false>(op, h, s, t, 0, 0)
+                                           : source_color_norm(op, s, t);
     return true;
 }
 

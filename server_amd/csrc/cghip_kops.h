@@ -44,7 +44,9 @@ enum KFastClass : int32_t {
 enum KSampleClass : int32_t {
     SC_GENERIC  = 0,
     SC_PLANAR8  = 1, /* ycbcr / ycbcra, every plane 1 channel 8 bit, Cb and Cr of one size, alpha the size of Y */
-    SC_PACKED8  = 2  /* bgra / rgba / argb / abgr in one 4-channel 8-bit plane */
+    SC_PACKED8  = 2, /* bgra / rgba / argb / abgr in one 4-channel 8-bit plane */
+    SC_PLANAR16 = 3, /* the same two layouts with 16-bit samples (fp32 filter weights) */
+    SC_PACKED16 = 4
 };
 
 /* register-resident surfaces the kernel has names for */

@@ -236,26 +236,30 @@ static void classify_fast(KOp& op, int frame_w)
 }
 
 /* which bilinear body of the general kernel fits the draw's source planes */
+static int g_generic_sampling = 0; /* test hook: every draw takes the generic per-format sampling path */
 static void classify_sampling(KOp& op)
 {
     op.sample_class = SC_GENERIC;
-    if (op.kind != KOP_DRAW_PLANES)
+    if (op.kind != KOP_DRAW_PLANES || g_generic_sampling)
         return;
     const int     pf = op.pixel_format;
     const KPlane& p0 = op.planes[0];
-    if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4 && p0.bits == 8) {
-        op.sample_class = SC_PACKED8;
+    if (p0.bits != 8 && p0.bits != 16)
+        return;
+    const bool wide = p0.bits == 16;
+    if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
+        op.sample_class = wide ? SC_PACKED16 : SC_PACKED8;
         return;
     }
     if ((pf == 5 && op.nplanes == 3) || (pf == 6 && op.nplanes == 4)) {
         for (int n = 0; n < op.nplanes; ++n)
-            if (op.planes[n].channels != 1 || op.planes[n].bits != 8)
+            if (op.planes[n].channels != 1 || op.planes[n].bits != p0.bits)
                 return;
         if (op.planes[1].w != op.planes[2].w || op.planes[1].h != op.planes[2].h)
             return;
         if (pf == 6 && (op.planes[3].w != p0.w || op.planes[3].h != p0.h))
             return;
-        op.sample_class = SC_PLANAR8;
+        op.sample_class = wide ? SC_PLANAR16 : SC_PLANAR8;
     }
 }
 
@@ -438,11 +442,12 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
 }
 
 /* ---- segments: which kernel runs which run of ops --------------------------------------------------------------
- * The 4-pixels-per-lane kernel is 3 to 6 times as fast per draw as the general one but takes only unit-scale
+ * The 4-pixels-per-lane kernel is about 3 times as fast per draw as the general one but takes only unit-scale
  * draws. A frame with one scaled box over a stack of full-screen layers should not pay the general price for the
  * whole stack, so the op list is cut into runs and every run gets its own launch; surfaces that are live across a
- * cut travel through HBM (KSpill). A cut costs a round trip of the frame (and a launch), which is worth about half a
- * full-screen draw of the general kernel: a two-state shortest path over the op list decides where cutting pays. */
+ * cut travel through HBM (KSpill). A cut costs a round trip of the frame (and a launch), which is worth about one
+ * full-screen draw moved from the general kernel to the fast one: a two-state shortest path over the op list decides
+ * where cutting pays. */
 static int g_force_general = 0;
 static int g_max_segments  = 8;
 static double g_cut_scale  = 1.0;
@@ -465,13 +470,16 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
     out->spill_mask = 0;
 
     /* 1. kernel class per op: min-cost path, states 0 = general, 1 = fast. Costs in picoseconds, measured with
-       tests/gpu_segments_probe.py: per pixel of a draw's box, a 16-bit / 8-bit planar layer
-       takes about 9 / 5 ps in the general kernel and 1.6 / 1.9 ps in the fast one; a cut costs a round trip of the
-       frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (about 4 us). */
+       tests/gpu_segments_probe.py and tests/gpu_probe.py: per pixel of a draw's box a layer
+       takes about 4.8 ps in the general kernel and 1.6 (16-bit) / 1.9 (8-bit) ps in the fast one; a cut costs a round
+       trip of the frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (about 4 us). */
     std::vector<uint8_t> cls((size_t)n, out->fast && !g_force_general ? 1 : 0);
     if (n > 0 && !out->fast && !g_force_general && g_max_segments > 1) {
-        const double per_px[2] = {fmt.bits == 16 ? 9.0 : 5.0, fmt.bits == 16 ? 1.6 : 1.9};
-        const double cut       = ((double)W * H * (fmt.bits == 16 ? 3.1 : 1.6) + 4e6) * g_cut_scale;
+        const double per_px[2] = {4.8, fmt.bits == 16 ? 1.6 : 1.9};
+        const double rt_px = fmt.bits == 16 ? 3.1 : 1.6, gap = 4e6;
+        /* into the fast kernel the whole frame makes the trip; into the general one, which may cover only the box of
+           its draws, this draw's box stands in for that */
+        auto cut_into = [&](int k, double area) { return (gap + rt_px * (k == 1 ? (double)W * H : area)) * g_cut_scale; };
         const double inf       = 1e300;
         std::vector<double>  cost((size_t)(n + 1) * 2, inf);
         std::vector<uint8_t> from((size_t)(n + 1) * 2, 0);
@@ -484,7 +492,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
                 if (k == 1 && !clr && o.fast_class == FC_NONE)
                     continue;
                 for (int j = 0; j < 2; ++j) {
-                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut : 0.0) + area * per_px[k];
+                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut_into(k, area) : 0.0) + area * per_px[k];
                     if (c < cost[(size_t)(i + 1) * 2 + k]) {
                         cost[(size_t)(i + 1) * 2 + k] = c;
                         from[(size_t)(i + 1) * 2 + k] = (uint8_t)j;
@@ -703,6 +711,7 @@ extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }
 
 /* test hooks: one launch of the general kernel per frame / at most n launches per frame (1 = never cut) */
 extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_general = on; }
+extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling = on; }
 extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }
 /* scales what the planner thinks a cut costs: 0 cuts at every change of class (tests: small frames never cut otherwise) */
 extern "C" void cghip_debug_cut_cost_scale(double scale) { cghip::g_cut_scale = scale >= 0.0 ? scale : 1.0; }

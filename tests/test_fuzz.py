@@ -143,3 +143,30 @@ def test_frames_cut_into_several_launches_equal_one_launch(bits):
     finally:
         m.close()
     assert n_cut > 80, n_cut
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
+def test_straight_line_sampling_classes_equal_the_generic_path(bits):
+    """The general kernel samples planar YCbCr(A) and packed 4-channel sources of either depth with straight-line
+    bilinear bodies (KSampleClass); they restate the generic per-format fetch operation for operation, so the frames
+    must be identical - at 16 bits too, where the oracle comparison is noise-limited."""
+    import server_amd as A
+    from fuzz_scenes import fuzz_scene
+    m = A.Mixer(channel_id=6, gpu=0)
+    L = A.lib()
+    try:
+        L.cghip_debug_force_general_kernel(1)
+        for seed in range(300):
+            sc = fuzz_scene(seed, bits)
+            cache = {}
+            classed = S.run_product(sc, mixer=m, planes_cache=cache)
+            L.cghip_debug_generic_sampling(1)
+            try:
+                generic = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_generic_sampling(0)
+            assert np.array_equal(classed, generic), (seed, S.diff_stats(classed, generic))
+    finally:
+        L.cghip_debug_force_general_kernel(0)
+        m.close()
