@@ -33,6 +33,9 @@ int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_
 /* Plans every frame as one launch of the general one-pixel-per-lane kernel, so tests can compare it with the
  * 4-pixels-per-lane kernel and with frames cut into several launches. */
 void cghip_debug_force_general_kernel(int on);
+/* The planner shrinks the composite of a layer / mix temporary to the box that was drawn into the temporary (outside it
+ * the draw is the identity); on = composites cover the whole frame as in the reference, so tests can compare. */
+void cghip_debug_full_frame_composites(int on);
 /* The general kernel samples the common plane layouts (KSampleClass) with straight-line bodies; on = every draw takes
  * the generic per-format path instead, so tests can compare the two. */
 void cghip_debug_generic_sampling(int on);

@@ -1208,7 +1208,13 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
     const int pf = op.pixel_format;
     if (SB == 8) {
         const uint32_t sel  = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
-        const u32x4    v    = load_at<u32x4>((GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 4, (uint32_t)sx * 4u);
+        u32x4          v;
+        if (op.flags & KF_SOLID) { /* one texel for every pixel (wave-uniform branch) */
+            const uint32_t t = load_at<uint32_t>((GB)op.ptr0, 0u);
+            v                = u32x4{t, t, t, t};
+        } else {
+            v = load_at<u32x4>((GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 4, (uint32_t)sx * 4u);
+        }
         const uint32_t m[4] = {v.x, v.y, v.z, v.w};
         const float    sc   = 1.0f / 255.0f;
 #pragma unroll
@@ -1220,8 +1226,14 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
     } else {
         const uint32_t slo = pf == 1 ? 0x03020100u : pf == 2 ? 0x03020504u : pf == 3 ? 0x05040706u : 0x01000302u;
         const uint32_t shi = pf == 1 ? 0x07060504u : pf == 2 ? 0x07060100u : pf == 3 ? 0x01000302u : 0x05040706u;
-        const GB       row = (GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 8;
-        const u32x4    v = load_at<u32x4>(row, (uint32_t)sx * 8u), w = load_at<u32x4>(row, (uint32_t)sx * 8u + 16u);
+        u32x4          v, w;
+        if (op.flags & KF_SOLID) {
+            const u32x2 t = load_at<u32x2>((GB)op.ptr0, 0u);
+            v = w = u32x4{t.x, t.y, t.x, t.y};
+        } else {
+            const GB row = (GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 8;
+            v = load_at<u32x4>(row, (uint32_t)sx * 8u), w = load_at<u32x4>(row, (uint32_t)sx * 8u + 16u);
+        }
         const uint32_t m[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
         const float    sc   = 1.0f / 65535.0f;
 #pragma unroll

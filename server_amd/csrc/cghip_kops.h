@@ -29,7 +29,8 @@ enum KOpFlags : uint32_t {
     KF_PROJECTIVE  = 1u << 6, /* texture_q != 1 somewhere: divide s,t by q per pixel */
     KF_RECT        = 1u << 7, /* axis-aligned quad with one affine map: coverage == bbox, no edge tests */
     KF_UNIT_SCALE  = 1u << 8, /* KF_RECT and plane 0 maps 1:1 onto output pixels at an integer offset */
-    KF_ADDITIVE    = 1u << 9  /* keyer::additive */
+    KF_ADDITIVE    = 1u << 9, /* keyer::additive */
+    KF_SOLID       = 1u << 10 /* KF_RECT and the source is one 1x1 packed texel (colour producer): every sample is it */
 };
 
 enum KFastClass : int32_t {

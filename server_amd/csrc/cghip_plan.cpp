@@ -11,6 +11,7 @@
  */
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstring>
 
@@ -198,9 +199,21 @@ static void classify_fast(KOp& op, int frame_w)
         return;
     }
     /* item draws always carry blend mode 0 (the layer's mode is applied by its composite); checked anyway */
-    if (op.kind != KOP_DRAW_PLANES || !(op.flags & KF_UNIT_SCALE) || op.blend_mode != 0)
+    if (op.kind != KOP_DRAW_PLANES || op.blend_mode != 0)
         return;
     const KPlane& p0 = op.planes[0];
+    /* the colour producer's frame: one 1x1 bgra texel stretched over a rectangle (core/producer/color/
+       color_producer.cpp). GL_LINEAR + CLAMP_TO_EDGE of a 1x1 texture returns that texel at every coordinate (both
+       filters lerp a texel with itself), so the draw is a constant fill of its box whatever the scale */
+    if ((op.flags & KF_RECT) && op.nplanes == 1 && p0.w == 1 && p0.h == 1 && p0.channels == 4 &&
+        op.pixel_format >= 1 && op.pixel_format <= 4 && (p0.bits == 8 || p0.bits == 16) && (op.x0 & 3) == 0 &&
+        ((op.x1 & 3) == 0 || op.x1 == frame_w)) {
+        op.flags |= KF_SOLID;
+        op.fast_class = FC_PACKED;
+        return;
+    }
+    if (!(op.flags & KF_UNIT_SCALE))
+        return;
     if ((p0.w & 3) != 0)
         return; /* rows must keep 4-texel groups aligned */
     /* every lane of the fast kernel owns 4 consecutive pixels and fetches them with one aligned vector load: the
@@ -236,6 +249,17 @@ static void classify_fast(KOp& op, int frame_w)
 }
 
 /* which bilinear body of the general kernel fits the draw's source planes */
+static int g_full_frame_composites = 0; /* test hook: composites of temporaries cover the frame, as in the reference */
+struct pixel_box {
+    int  x0 = INT_MAX, y0 = INT_MAX, x1 = INT_MIN, y1 = INT_MIN;
+    bool empty() const { return x0 >= x1 || y0 >= y1; }
+    void add(int ax0, int ay0, int ax1, int ay1)
+    {
+        if (ax0 >= ax1 || ay0 >= ay1)
+            return;
+        x0 = std::min(x0, ax0), y0 = std::min(y0, ay0), x1 = std::max(x1, ax1), y1 = std::max(y1, ay1);
+    }
+};
 static int g_generic_sampling = 0; /* test hook: every draw takes the generic per-format sampling path */
 static void classify_sampling(KOp& op)
 {
@@ -472,11 +496,11 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
     /* 1. kernel class per op: min-cost path, states 0 = general, 1 = fast. Costs in picoseconds, measured with
        tests/gpu_segments_probe.py and tests/gpu_probe.py: per pixel of a draw's box a layer
        takes about 4.8 ps in the general kernel and 1.6 (16-bit) / 1.9 (8-bit) ps in the fast one; a cut costs a round
-       trip of the frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (about 4 us). */
+       trip of the frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (about 6 us with the extra launch's ramp). */
     std::vector<uint8_t> cls((size_t)n, out->fast && !g_force_general ? 1 : 0);
     if (n > 0 && !out->fast && !g_force_general && g_max_segments > 1) {
         const double per_px[2] = {4.8, fmt.bits == 16 ? 1.6 : 1.9};
-        const double rt_px = fmt.bits == 16 ? 3.1 : 1.6, gap = 4e6;
+        const double rt_px = fmt.bits == 16 ? 3.1 : 1.6, gap = 6e6;
         /* into the fast kernel the whole frame makes the trip; into the general one, which may cover only the box of
            its draws, this draw's box stands in for that */
         auto cut_into = [&](int k, double area) { return (gap + rt_px * (k == 1 ? (double)W * H : area)) * g_cut_scale; };
@@ -484,15 +508,22 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         std::vector<double>  cost((size_t)(n + 1) * 2, inf);
         std::vector<uint8_t> from((size_t)(n + 1) * 2, 0);
         cost[0] = cost[1] = 0.0;
+        auto box_area = [&](int i) { /* a CLEAR in front of a draw is priced as that draw when it opens a run */
+            while (i < n && ops[(size_t)i].kind == KOP_CLEAR)
+                ++i;
+            return i < n ? (double)std::max(0, ops[(size_t)i].x1 - ops[(size_t)i].x0) *
+                               std::max(0, ops[(size_t)i].y1 - ops[(size_t)i].y0)
+                         : 0.0;
+        };
         for (int i = 0; i < n; ++i) {
             const KOp&   o    = ops[(size_t)i];
             const bool   clr  = o.kind == KOP_CLEAR;
-            const double area = clr ? 0.0 : (double)std::max(0, o.x1 - o.x0) * std::max(0, o.y1 - o.y0);
+            const double area = clr ? 0.0 : box_area(i), open_area = box_area(i);
             for (int k = 0; k < 2; ++k) {
                 if (k == 1 && !clr && o.fast_class == FC_NONE)
                     continue;
                 for (int j = 0; j < 2; ++j) {
-                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut_into(k, area) : 0.0) + area * per_px[k];
+                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut_into(k, open_area) : 0.0) + area * per_px[k];
                     if (c < cost[(size_t)(i + 1) * 2 + k]) {
                         cost[(size_t)(i + 1) * 2 + k] = c;
                         from[(size_t)(i + 1) * 2 + k] = (uint8_t)j;
@@ -624,6 +655,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
        device.cpp:207-209) */
     std::vector<int> reg((size_t)nsurfaces, KS_NONE);
     int              owner[KS_COUNT];
+    pixel_box        drawn[KS_COUNT]; /* what has been drawn into a register surface since its CLEAR */
     for (int& o : owner)
         o = -1;
     reg[0]          = KS_RGBA0;
@@ -648,6 +680,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
                 c.kind = KOP_CLEAR;
                 c.dst  = r;
                 out->ops.push_back(c);
+                drawn[r] = pixel_box();
                 if (r == KS_RGBA1 || r == KS_RGBA2)
                     out->full = true;
                 return r;
@@ -670,6 +703,23 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
                         "frame needs more than 2 live RGBA temporaries or 2 live key textures at once");
         if (surfaces[d.target].channels == 1 && d.source_surface >= 0)
             return fail(CGHIP_ERR_INVALID, "surface-to-key draws do not exist in the reference renderer");
+        /* A temporary is composited with a full-frame draw (image_mixer.cpp:207-225), but outside of what was drawn
+           into it since its CLEAR it is zero, and a zero source leaves the target as it is: fore = 0, the blend
+           colour is multiplied by fore.a = 0, and back passes through both keyers unchanged (shader.frag:424-434).
+           So the draw only has to cover that box (widened to whole 4-pixel groups for the 4-pixels-per-lane kernel).
+           Not for the HSL modes, whose blend colour can be inf for unpremultiplied backgrounds, nor with invert or
+           colour adjustments, which turn a zero source into something else. */
+        if (op.kind == KOP_DRAW_SURFACE && !(op.blend_mode >= 25 && op.blend_mode <= 28) &&
+            !(op.flags & (KF_INVERT | KF_LEVELS | KF_CSB | KF_CHROMA)) && !g_full_frame_composites) {
+            const pixel_box& d = drawn[op.src_surface];
+            if (d.empty())
+                continue; /* nothing was drawn into the temporary */
+            op.x0 = std::max(op.x0, d.x0 & ~3), op.x1 = std::min(op.x1, std::min(fmt->width, (d.x1 + 3) & ~3));
+            op.y0 = std::max(op.y0, d.y0), op.y1 = std::min(op.y1, d.y1);
+            if (op.x0 >= op.x1 || op.y0 >= op.y1)
+                continue;
+        }
+        drawn[op.dst].add(op.x0, op.y0, op.x1, op.y1);
         classify_fast(op, fmt->width); /* dst is known now */
         classify_sampling(op);
         out->ops.push_back(op);
@@ -712,6 +762,7 @@ extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }
 /* test hooks: one launch of the general kernel per frame / at most n launches per frame (1 = never cut) */
 extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_general = on; }
 extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling = on; }
+extern "C" void cghip_debug_full_frame_composites(int on) { cghip::g_full_frame_composites = on; }
 extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }
 /* scales what the planner thinks a cut costs: 0 cuts at every change of class (tests: small frames never cut otherwise) */
 extern "C" void cghip_debug_cut_cost_scale(double scale) { cghip::g_cut_scale = scale >= 0.0 ? scale : 1.0; }

@@ -114,17 +114,26 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     ops = []
     s = 9000 + 131 * seed
     for i in range(rng.randint(1, 7)):
-        f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420"])
+        f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420",
+                        "solid"])
         kind = rng.choice(["smooth", "noise", "video"])
-        if f in ("bgra", "rgba", "argb", "abgr"):
+        solid_box = None
+        if f == "solid":  # the colour producer: one 1x1 texel stretched over a rectangle on 4-pixel columns
+            src = S.frame(rng.choice(["bgra", "rgba", "argb", "abgr"]), [(1, 1, 4, "noise", s + i)], bits)
+            if rng.random() < 0.5:
+                x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
+                y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
+                if x1 > x0 and y1 > y0:
+                    solid_box = dict(fill_translation=[x0 / W, y0 / H], fill_scale=[(x1 - x0) / W, (y1 - y0) / H])
+        elif f in ("bgra", "rgba", "argb", "abgr"):
             src = S.frame(f, [(W, H, 4, rng.choice(["premul", "noise", "smooth"]), s + i)], bits)
         else:
             src = S.ycbcr(W, H, f[-3:], kind, s + i, bits=bits, alpha=f.startswith("ycbcra"))
-        t = {}
+        t = dict(solid_box or {})
         r = rng.random
         if r() < 0.7:
             t["opacity"] = rng.choice([1.0, 0.5, 0.25, round(r(), 3), 0.73])
-        if r() < 0.3:  # crop on 4-pixel columns (any row)
+        if f != "solid" and r() < 0.3:  # crop on 4-pixel columns (any row)
             x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
             y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
             if x1 > x0 and y1 > y0:

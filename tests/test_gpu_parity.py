@@ -148,6 +148,34 @@ def test_fast_kernel_equals_general_kernel(mixer):
         assert (so["max"] <= 1 and so["gt0"] <= 1e-4) if bits == 8 else (so["gt2"] <= 1e-4), so
 
 
+def test_composites_of_temporaries_shrunk_to_what_was_drawn(mixer):
+    """The planner composites a layer temporary only over the box that was drawn into it: outside it the source is
+    zero and the draw is the identity for every blend mode it is applied to. Over an unpremultiplied background with
+    alpha down to 0 (the blend divides by it), every mode must equal the full-frame composite and the oracle bit for
+    bit."""
+    import server_amd as A
+    L = A.lib()
+    W, H = 200, 120
+    for name in S.BLEND_NAMES:
+        sc = S.scene("shrink_" + name, W, H, [
+            S.layer(S.bgra(W, H, "smooth", 900), fill_scale=[0.7, 0.8]),  # leaves alpha 0 to the right and below
+            S.layer(S.bgra(W, H, "noise", 901), opacity=0.6, fill_scale=[0.8, 0.7]),
+            S.layer(S.bgra(64, 48, "premul", 902), blend_mode=name, opacity=0.8, fill_scale=[0.33, 0.41],
+                    fill_translation=[0.31, 0.27]),
+            S.layer(S.ycbcr(W, H, "420", "video", 903), opacity=0.5, blend_mode=name, fill_scale=[0.5, 0.5],
+                    fill_translation=[0.45, 0.4], angle=0.3)])
+        cache = {}
+        shrunk = S.run_product(sc, mixer=mixer, planes_cache=cache)
+        L.cghip_debug_full_frame_composites(1)
+        try:
+            full = S.run_product(sc, mixer=mixer, planes_cache=cache)
+        finally:
+            L.cghip_debug_full_frame_composites(0)
+        assert np.array_equal(shrunk, full), (name, S.diff_stats(shrunk, full))
+        ref = S.run_oracle(sc, "cpu", cache)
+        assert np.array_equal(shrunk, ref), (name, S.diff_stats(shrunk, ref))
+
+
 @pytest.mark.parametrize("bits", [8, 16])
 def test_mixed_frame_is_cut_into_launches_by_the_default_policy(mixer, bits):
     """A 1080p rundown of full-screen layers around one scaled box and a keyed, scaled pair: the planner's own cost
