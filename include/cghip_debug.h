@@ -36,6 +36,9 @@ void cghip_debug_force_general_kernel(int on);
 /* The planner shrinks the composite of a layer / mix temporary to the box that was drawn into the temporary (outside it
  * the draw is the identity); on = composites cover the whole frame as in the reference, so tests can compare. */
 void cghip_debug_full_frame_composites(int on);
+/* The planner drops draws that a later full-frame opaque layer hides (and keys / temporaries only they consumed);
+ * on = every draw of the reference is executed, so tests can compare. */
+void cghip_debug_keep_hidden_ops(int on);
 /* The general kernel samples the common plane layouts (KSampleClass) with straight-line bodies; on = every draw takes
  * the generic per-format path instead, so tests can compare the two. */
 void cghip_debug_generic_sampling(int on);

@@ -1386,8 +1386,9 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
             });
         }
         /* one combined test, one merge point: a chain of early `continue`s made the compiler copy all 24
-           loop-carried registers at every exit. x0, x1 are multiples of 4: a lane is all in or all out. */
-        if (clr | !((y >= h.y0) & (y < h.y1) & (px0 >= h.x0) & (px0 < h.x1)))
+           loop-carried registers at every exit. A lane takes part if any of its 4 pixels is in the box; x0, x1 are
+           multiples of 4 (a lane is all in or all out) unless the op carries KF_EDGE, see below. */
+        if (clr | !((y >= h.y0) & (y < h.y1) & (px0 > h.x0 - P) & (px0 < h.x1)))
             continue;
         const int  sx = px0 + h.unit_dx, sy = y + h.unit_dy;
         const bool s16 = h.bits0 == 16;
@@ -1428,6 +1429,13 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
         if (h.flags & KF_CSB) {
             const CsbV bp(op);
             static_for<0, P>([&](auto I) { csb(col[decltype(I)::value], bp); });
+        }
+        if (h.flags & KF_EDGE) { /* a box edge inside a lane's 4 pixels: a zero source leaves the target as it is */
+            const uint32_t span = (uint32_t)(h.x1 - h.x0); /* one unsigned compare per pixel: x0 <= x < x1 */
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                col[i] = sel4((uint32_t)(px0 + i - h.x0) < span, col[i], f4{0, 0, 0, 0});
+            });
         }
         const bool simple = h.local_key == KS_NONE && h.layer_key == KS_NONE && !(h.flags & (KF_INVERT | KF_ADDITIVE));
         if (h.dst >= KS_KEY0) {

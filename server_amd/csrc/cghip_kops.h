@@ -30,6 +30,7 @@ enum KOpFlags : uint32_t {
     KF_RECT        = 1u << 7, /* axis-aligned quad with one affine map: coverage == bbox, no edge tests */
     KF_UNIT_SCALE  = 1u << 8, /* KF_RECT and plane 0 maps 1:1 onto output pixels at an integer offset */
     KF_ADDITIVE    = 1u << 9, /* keyer::additive */
+    KF_EDGE        = 1u << 11, /* fast kernel: x0 or x1 is not a multiple of 4, lanes on the box edge mask their pixels */
     KF_SOLID       = 1u << 10 /* KF_RECT and the source is one 1x1 packed texel (colour producer): every sample is it */
 };
 

@@ -205,10 +205,15 @@ static void classify_fast(KOp& op, int frame_w)
     /* the colour producer's frame: one 1x1 bgra texel stretched over a rectangle (core/producer/color/
        color_producer.cpp). GL_LINEAR + CLAMP_TO_EDGE of a 1x1 texture returns that texel at every coordinate (both
        filters lerp a texel with itself), so the draw is a constant fill of its box whatever the scale */
+    /* A lane owns 4 consecutive pixels. A box edge that is not on a 4-pixel column leaves a lane partly covered: it
+       zeroes the source colour of its uncovered pixels (KF_EDGE), and a zero source leaves the target as it is - unless
+       the draw inverts, which turns zero into one. */
+    const bool edge = (op.x0 & 3) != 0 || ((op.x1 & 3) != 0 && op.x1 != frame_w);
+    if (edge && (op.flags & KF_INVERT))
+        return;
     if ((op.flags & KF_RECT) && op.nplanes == 1 && p0.w == 1 && p0.h == 1 && p0.channels == 4 &&
-        op.pixel_format >= 1 && op.pixel_format <= 4 && (p0.bits == 8 || p0.bits == 16) && (op.x0 & 3) == 0 &&
-        ((op.x1 & 3) == 0 || op.x1 == frame_w)) {
-        op.flags |= KF_SOLID;
+        op.pixel_format >= 1 && op.pixel_format <= 4 && (p0.bits == 8 || p0.bits == 16)) {
+        op.flags |= KF_SOLID | (edge ? KF_EDGE : 0u);
         op.fast_class = FC_PACKED;
         return;
     }
@@ -217,11 +222,14 @@ static void classify_fast(KOp& op, int frame_w)
     if ((p0.w & 3) != 0)
         return; /* rows must keep 4-texel groups aligned */
     /* every lane of the fast kernel owns 4 consecutive pixels and fetches them with one aligned vector load: the
-       op's pixel box and its source offset must keep those groups whole and inside the plane */
-    if ((op.x0 & 3) != 0 || (op.x1 & 3) != 0 || (op.unit_dx & 3) != 0)
+       op's source offset must keep those groups whole, and the groups its box touches must be inside the plane */
+    if ((op.unit_dx & 3) != 0)
         return;
-    if (op.x0 + op.unit_dx < 0 || op.x1 + op.unit_dx > p0.w || op.y0 + op.unit_dy < 0 || op.y1 + op.unit_dy > p0.h)
+    const int ax0 = op.x0 & ~3, ax1 = (op.x1 + 3) & ~3; /* what the lanes on the edges load */
+    if (ax0 + op.unit_dx < 0 || ax1 + op.unit_dx > p0.w || op.y0 + op.unit_dy < 0 || op.y1 + op.unit_dy > p0.h)
         return;
+    if (edge)
+        op.flags |= KF_EDGE;
     const int pf = op.pixel_format;
     if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
         op.fast_class = FC_PACKED;
@@ -463,6 +471,66 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
         }
     }
     return 1;
+}
+
+/* ---- draws nobody can see -----------------------------------------------------------------------------------
+ * A full-frame layer whose source has no alpha channel (YCbCr, bgr / rgb, gray, luma), drawn at opacity 1 with the
+ * linear keyer and no key, chroma key or invert, replaces the frame: fore.a = 1, so the keyer computes fore + 0 * back
+ * (shader.frag:430-433), which does not depend on back. Everything drawn to the frame before it is invisible - a
+ * looping background under a full-screen clip, say - and so is every key or temporary only such draws consumed. The
+ * GL mixer draws it all; here a backward liveness pass over the op list drops it. */
+static int g_keep_hidden_ops = 0; /* test hook */
+
+static bool replaces_frame(const KOp& o, const cghip_format& fmt)
+{
+    const int pf = o.pixel_format;
+    return o.kind == KOP_DRAW_PLANES && o.dst == KS_RGBA0 && (o.flags & KF_RECT) && o.x0 == 0 && o.y0 == 0 &&
+           o.x1 == fmt.width && o.y1 == fmt.height && o.blend_mode == 0 && o.local_key == KS_NONE &&
+           o.layer_key == KS_NONE && !(o.flags & (KF_INVERT | KF_ADDITIVE | KF_CHROMA)) && o.opacity == 1.0f &&
+           (pf == 0 || pf == 5 || pf == 7 || pf == 8 || pf == 9 || pf == 10);
+}
+
+static void drop_hidden_ops(const cghip_format& fmt, frame_plan* out)
+{
+    if (g_keep_hidden_ops)
+        return;
+    std::vector<KOp>&    ops = out->ops;
+    std::vector<uint8_t> keep(ops.size(), 0);
+    uint32_t             live = 1u << KS_RGBA0; /* surfaces whose value at this point still matters */
+    bool                 any_dropped = false;
+    for (size_t i = ops.size(); i-- > 0;) {
+        const KOp&     o   = ops[i];
+        const uint32_t dst = o.dst >= 0 && o.dst < KS_COUNT ? 1u << o.dst : 0u;
+        if (!(live & dst)) {
+            any_dropped = true;
+            continue;
+        }
+        keep[i] = 1;
+        if (o.kind == KOP_CLEAR) {
+            live &= ~dst;
+            continue;
+        }
+        if (replaces_frame(o, fmt))
+            live &= ~dst;
+        for (int s : {o.local_key, o.layer_key, o.kind == KOP_DRAW_SURFACE ? o.src_surface : (int)KS_NONE})
+            if (s >= 0 && s < KS_COUNT)
+                live |= 1u << s;
+    }
+    if (!any_dropped)
+        return;
+    size_t n = 0;
+    for (size_t i = 0; i < ops.size(); ++i)
+        if (keep[i])
+            ops[n++] = ops[i];
+    ops.resize(n);
+    out->full = false;
+    out->fast = true;
+    for (const KOp& o : ops) {
+        if (o.dst == KS_RGBA1 || o.dst == KS_RGBA2)
+            out->full = true;
+        if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
+            out->fast = false;
+    }
 }
 
 /* ---- segments: which kernel runs which run of ops --------------------------------------------------------------
@@ -731,6 +799,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
     for (const KOp& o : out->ops)
         if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
             out->fast = false;
+    drop_hidden_ops(*fmt, out);
     split_into_segments(*fmt, out);
     return CGHIP_OK;
 }
@@ -762,6 +831,7 @@ extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }
 /* test hooks: one launch of the general kernel per frame / at most n launches per frame (1 = never cut) */
 extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_general = on; }
 extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling = on; }
+extern "C" void cghip_debug_keep_hidden_ops(int on) { cghip::g_keep_hidden_ops = on; }
 extern "C" void cghip_debug_full_frame_composites(int on) { cghip::g_full_frame_composites = on; }
 extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }
 /* scales what the planner thinks a cut costs: 0 cuts at every change of class (tests: small frames never cut otherwise) */

@@ -117,29 +117,31 @@ def fuzz_fast_scene(seed, bits=8, full=False):
         f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420",
                         "solid"])
         kind = rng.choice(["smooth", "noise", "video"])
-        solid_box = None
         if f == "solid":  # the colour producer: one 1x1 texel stretched over a rectangle on 4-pixel columns
             src = S.frame(rng.choice(["bgra", "rgba", "argb", "abgr"]), [(1, 1, 4, "noise", s + i)], bits)
-            if rng.random() < 0.5:
-                x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
-                y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
-                if x1 > x0 and y1 > y0:
-                    solid_box = dict(fill_translation=[x0 / W, y0 / H], fill_scale=[(x1 - x0) / W, (y1 - y0) / H])
         elif f in ("bgra", "rgba", "argb", "abgr"):
             src = S.frame(f, [(W, H, 4, rng.choice(["premul", "noise", "smooth"]), s + i)], bits)
         else:
             src = S.ycbcr(W, H, f[-3:], kind, s + i, bits=bits, alpha=f.startswith("ycbcra"))
-        t = dict(solid_box or {})
+        t = {}
         r = rng.random
+        if r() < 0.1:
+            t["invert"] = 1
+        step = 4 if t.get("invert") else rng.choice([1, 4])  # box edges inside a lane's 4 pixels need a non-inverting draw
+        if f == "solid" and r() < 0.5:
+            x0, x1 = sorted(rng.sample(range(0, W + 1, step), 2))
+            y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
+            if x1 > x0 and y1 > y0:
+                t.update(fill_translation=[x0 / W, y0 / H], fill_scale=[(x1 - x0) / W, (y1 - y0) / H])
         if r() < 0.7:
             t["opacity"] = rng.choice([1.0, 0.5, 0.25, round(r(), 3), 0.73])
-        if f != "solid" and r() < 0.3:  # crop on 4-pixel columns (any row)
-            x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
+        if f != "solid" and r() < 0.3:  # crop (any row)
+            x0, x1 = sorted(rng.sample(range(0, W + 1, step), 2))
             y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
             if x1 > x0 and y1 > y0:
                 t["crop_ul"], t["crop_lr"] = [x0 / W, y0 / H], [x1 / W, y1 / H]
         if r() < 0.2:
-            x0, x1 = sorted(rng.sample(range(0, W + 1, 4), 2))
+            x0, x1 = sorted(rng.sample(range(0, W + 1, step), 2))
             y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
             if x1 > x0 and y1 > y0:
                 t["clip_translation"], t["clip_scale"] = [x0 / W, y0 / H], [(x1 - x0) / W, (y1 - y0) / H]
@@ -152,8 +154,6 @@ def fuzz_fast_scene(seed, bits=8, full=False):
                      contrast=round(rng.uniform(0.6, 1.4), 2))
         if r() < 0.2:
             t.update(dict(S.CHROMA, chroma_target_hue=rng.choice([120.0, 240.0, 30.0]), chroma_show_mask=1 if r() < 0.2 else 0))
-        if r() < 0.1:
-            t["invert"] = 1
         if r() < 0.25:
             t["is_key"] = 1
         elif full and r() < 0.35:  # the layer goes through a layer temporary and is composited with a blend mode

@@ -32,8 +32,8 @@ class KOp(C.Structure):
 
 
 KOP_CLEAR, KOP_DRAW_PLANES, KOP_DRAW_SURFACE = 0, 1, 2
-KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE, KF_SOLID = \
-    [1 << i for i in range(11)]
+KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE, KF_SOLID, KF_EDGE = \
+    [1 << i for i in range(12)]
 KS_RGBA0, KS_RGBA1, KS_RGBA2, KS_KEY0, KS_KEY1 = range(5)
 
 

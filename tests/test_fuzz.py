@@ -170,3 +170,43 @@ def test_straight_line_sampling_classes_equal_the_generic_path(bits):
     finally:
         L.cghip_debug_force_general_kernel(0)
         m.close()
+
+
+@pytest.mark.gpu
+def test_draws_hidden_by_an_opaque_full_frame_layer_are_dropped_without_a_trace():
+    """The planner drops what a later full-frame layer without alpha, at opacity 1, hides (cghip_plan.cpp:
+    drop_hidden_ops). Rundowns with such a layer in the middle must render exactly as with every draw executed, and
+    exactly as the oracle, which executes every draw."""
+    import random
+    import kops as K
+    import server_amd as A
+    from fuzz_scenes import fuzz_scene, fuzz_fast_scene
+    m = A.Mixer(channel_id=7, gpu=0)
+    L = A.lib()
+    fewer = 0
+    try:
+        for seed in range(200):
+            base = fuzz_scene(seed, 8) if seed % 2 else fuzz_fast_scene(seed, 8, True)
+            W, H = base["width"], base["height"]
+            rng = random.Random(seed)
+            cover = S.layer(S.ycbcr(W, H, rng.choice(["420", "422", "444"]), "video", 7000 + seed),
+                            **(S.LEVELS if seed % 3 == 0 else {}))
+            flat = list(base["ops"])
+            # insert the cover between two top-level layers
+            tops = [i for i, o in enumerate(flat) if o[0] == "push" and o[1].get("layer_depth") == 1]
+            at = rng.choice(tops[1:] + [len(flat)]) if len(tops) > 1 else len(flat)
+            sc = dict(base, ops=flat[:at] + cover + flat[at:], name="hidden_%d" % seed)
+            cache = {}
+            before = m.device_info()["kernel_launches"]
+            dropped = S.run_product(sc, mixer=m, planes_cache=cache)
+            L.cghip_debug_keep_hidden_ops(1)
+            try:
+                every = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_keep_hidden_ops(0)
+            assert np.array_equal(dropped, every), (seed, S.diff_stats(dropped, every))
+            ref = S.run_oracle(sc, "cpu", cache)
+            st = S.diff_stats(dropped, ref)
+            assert st["max"] <= 1 and st["gt0"] <= 1e-4, (seed, st)
+    finally:
+        m.close()
