@@ -446,8 +446,13 @@ DEV float BlendReflectf(float b, float s) { return s == 1.0f ? s : __builtin_fmi
 #define B3R(f) f3{f(s.x, b.x), f(s.y, b.y), f(s.z, b.z)}
 
 /* shader.frag:387-422 with its aliasing kept: 12 (soft_light) and >= 29 (mix) fall through to normal,
- * 25 ("contrast") runs BlendHue. b = back, s = fore. The mode is wave-uniform. */
-__device__ __noinline__ f3 get_blend_color(int mode, f3 b, f3 s)
+ * 25 ("contrast") runs BlendHue. b = back, s = fore. The mode is a template parameter; get_blend_color() below
+ * picks the body with a SCALAR switch. When the switch itself sat in the out-of-line function, the mode arrived in a
+ * VGPR (function ABI) and the switch was lowered as divergent control flow: ~170 exec-mask blocks walked per pixel.
+ * (The bodies cannot be inlined into the op loops instead: with 28 more paths to the loop latch the compiler no
+ * longer proves the op fields uniform and refuses the scalar loads.) */
+template <int mode>
+DEV f3 blend_color(f3 b, f3 s)
 {
     switch (mode) {
         case 1: return f3{__builtin_fmaxf(s.x, b.x), __builtin_fmaxf(s.y, b.y), __builtin_fmaxf(s.z, b.z)};
@@ -497,6 +502,43 @@ __device__ __noinline__ f3 get_blend_color(int mode, f3 b, f3 s)
         }
         default: return s;
     }
+}
+
+/* f(std::integral_constant<int, m>) for the executed mode m (0 for the modes that alias to normal); mode is
+ * wave-uniform */
+template <class F>
+DEV void dispatch_mode(int mode, F&& f)
+{
+    switch (__builtin_amdgcn_readfirstlane(mode)) {
+#define M(k) case k: f(std::integral_constant<int, k>{}); break;
+        M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21)
+        M(22) M(23) M(24) M(25) M(26) M(27) M(28)
+#undef M
+        default: f(std::integral_constant<int, 0>{}); break;
+    }
+}
+
+/* run-time mode, out of line */
+__device__ __noinline__ f3 get_blend_color(int mode, f3 b, f3 s)
+{
+    f3 r = s;
+    dispatch_mode(mode, [&](auto m) { r = blend_color<decltype(m)::value>(b, s); });
+    return r;
+}
+
+/* the same for a lane's four pixels with ONE call: after a call the caller reloads the SGPRs it held from memory,
+ * and at the three waves per SIMD of the kernel variant that blends, four such stalls per op are not hidden */
+struct F3x4 { /* plain members, no array: passed and returned in VGPRs */
+    f3 v0, v1, v2, v3;
+};
+__device__ __noinline__ F3x4 get_blend_color4(int mode, F3x4 b, F3x4 s)
+{
+    F3x4 r = s;
+    dispatch_mode(mode, [&](auto m) {
+        constexpr int M = decltype(m)::value;
+        r = F3x4{blend_color<M>(b.v0, s.v0), blend_color<M>(b.v1, s.v1), blend_color<M>(b.v2, s.v2), blend_color<M>(b.v3, s.v3)};
+    });
+    return r;
 }
 
 /* shader.frag:474-521 from GL texels to the internal (b,g,r,a) vector */
@@ -586,8 +628,15 @@ DEV f4 shade_adjust(const KOp& op, f4 color)
 /* shader.frag:532-541: keys, opacity, invert, blend. No FMA contraction in here: llvmpipe evaluates these
  * unfused, and with "nice" opacities (0.5, 0.25 ...) the UNORM store that follows hits exact .5 ties that only
  * the same sequence of roundings resolves the same way. Returns the UNQUANTISED result, internal order. */
-template <bool BLEND>
-DEV f4 shade_blend(const KOp& op, f4 color, float lkey, float ykey, f4 back)
+enum : int { MODE_RUNTIME = -2, MODE_NONE = -1 }; /* or the blend mode itself, inline */
+struct BlendArgs { /* what shade_blend reads of an op, by value */
+    uint32_t flags;
+    int32_t  local_key, layer_key;
+    float    opacity;
+    int32_t  blend_mode;
+};
+template <int MODE, class P>
+DEV f4 shade_blend(const P& op, f4 color, float lkey, float ykey, f4 back)
 {
 #pragma clang fp contract(off)
     /* The optional steps are made unconditional with neutral operands instead of wave-uniform branches (which
@@ -602,10 +651,18 @@ DEV f4 shade_blend(const KOp& op, f4 color, float lkey, float ykey, f4 back)
     const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
     f4 fore = {__builtin_fmaf(color.x, im, ia0), __builtin_fmaf(color.y, im, ia0), __builtin_fmaf(color.z, im, ia0),
                __builtin_fmaf(color.w, im, ia0)};
-    if (BLEND && op.blend_mode != 0) { /* shader.frag:427-428 */
+    bool blend = MODE >= 0;
+    if constexpr (MODE == MODE_RUNTIME)
+        blend = op.blend_mode != 0;
+    if (blend) { /* shader.frag:427-428 */
         const float ba = back.w + 0.0000001f, fa = fore.w + 0.0000001f;
-        const f3    bc = get_blend_color(op.blend_mode, f3{fdiv(back.x, ba), fdiv(back.y, ba), fdiv(back.z, ba)},
-                                      f3{fdiv(fore.x, fa), fdiv(fore.y, fa), fdiv(fore.z, fa)});
+        const f3    B = {fdiv(back.x, ba), fdiv(back.y, ba), fdiv(back.z, ba)};
+        const f3    F = {fdiv(fore.x, fa), fdiv(fore.y, fa), fdiv(fore.z, fa)};
+        f3          bc;
+        if constexpr (MODE == MODE_RUNTIME)
+            bc = get_blend_color(op.blend_mode, B, F);
+        else
+            bc = blend_color<(MODE >= 0 ? MODE : 0)>(B, F);
         fore.x = bc.x * fore.w, fore.y = bc.y * fore.w, fore.z = bc.z * fore.w;
     }
     /* shader.frag:429-433: additive keyer = fore + back, linear = fore + (1 - fore.a) * back */
@@ -613,10 +670,46 @@ DEV f4 shade_blend(const KOp& op, f4 color, float lkey, float ykey, f4 back)
     return f4{fore.x + ia * back.x, fore.y + ia * back.y, fore.z + ia * back.z, fore.w + ia * back.w};
 }
 
-template <bool BLEND = true>
+/* shade_blend<MODE_RUNTIME> with a non-zero mode for four pixels, operation for operation, around one call of
+ * get_blend_color4; results quantised into D */
+template <int BITS>
+DEV void shade_blend_mode4(const BlendArgs op, const f4 col[4], f4 D[4], const float K0[4], const float K1[4])
+{
+#pragma clang fp contract(off)
+    const bool  inv = op.flags & KF_INVERT;
+    const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
+    f4          fore[4];
+    f3          B[4], F[4];
+    static_for<0, 4>([&](auto I) {
+        constexpr int i  = decltype(I)::value;
+        const float   k1 = op.local_key != KS_NONE ? (op.local_key == KS_KEY1 ? K1[i] : K0[i]) : 1.0f;
+        const float   k2 = op.layer_key != KS_NONE ? (op.layer_key == KS_KEY1 ? K1[i] : K0[i]) : 1.0f;
+        f4            c  = col[i];
+        c.x *= k1, c.y *= k1, c.z *= k1, c.w *= k1;
+        c.x *= k2, c.y *= k2, c.z *= k2, c.w *= k2;
+        c.x *= op.opacity, c.y *= op.opacity, c.z *= op.opacity, c.w *= op.opacity;
+        fore[i] = f4{__builtin_fmaf(c.x, im, ia0), __builtin_fmaf(c.y, im, ia0), __builtin_fmaf(c.z, im, ia0),
+                     __builtin_fmaf(c.w, im, ia0)};
+        const float ba = D[i].w + 0.0000001f, fa = fore[i].w + 0.0000001f;
+        B[i] = f3{fdiv(D[i].x, ba), fdiv(D[i].y, ba), fdiv(D[i].z, ba)};
+        F[i] = f3{fdiv(fore[i].x, fa), fdiv(fore[i].y, fa), fdiv(fore[i].z, fa)};
+    });
+    const F3x4 r     = get_blend_color4(op.blend_mode, F3x4{B[0], B[1], B[2], B[3]}, F3x4{F[0], F[1], F[2], F[3]});
+    const f3   bc[4] = {r.v0, r.v1, r.v2, r.v3};
+    static_for<0, 4>([&](auto I) {
+        constexpr int i  = decltype(I)::value;
+        const float   fw = fore[i].w;
+        const f3      f  = {bc[i].x * fw, bc[i].y * fw, bc[i].z * fw};
+        const float   ia = (op.flags & KF_ADDITIVE) ? 1.0f : 1.0f - fw;
+        D[i] = f4{quantize<BITS>(f.x + ia * D[i].x), quantize<BITS>(f.y + ia * D[i].y), quantize<BITS>(f.z + ia * D[i].z),
+                  quantize<BITS>(fw + ia * D[i].w)};
+    });
+}
+
+/* the whole of shader.frag:523-541 */
 DEV f4 shade(const KOp& op, f4 color, float lkey, float ykey, f4 back)
 {
-    return shade_blend<BLEND>(op, shade_adjust(op, color), lkey, ykey, back);
+    return shade_blend<MODE_RUNTIME>(op, shade_adjust(op, color), lkey, ykey, back);
 }
 
 /* ------------------------------------------------------------------ the compositor */
@@ -898,7 +991,7 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
     for (int n = 0; n < nops && row_live; ++n) {
-        const KOp& op  = ops[n];
+        const KOp& op  = ops[__builtin_amdgcn_readfirstlane(n)]; /* n is uniform; say so (see dispatch_mode) */
         const HotG h   = load_hot_g(op);
         const bool clr = h.kind == KOP_CLEAR;
         {
@@ -1370,7 +1463,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
     for (int n = 0; n < nops && row_live; ++n) {
-        const KOp&  op  = ops[n];
+        const KOp&  op  = ops[__builtin_amdgcn_readfirstlane(n)]; /* n is uniform; say so (see dispatch_mode) */
         const HotOp h   = load_hot(op);
         const bool  clr = h.kind == KOP_CLEAR;
         const bool  clr0 = clr & (h.dst == KS_KEY0), clr1 = clr & (h.dst == KS_KEY1);
@@ -1448,13 +1541,7 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
             const bool one_key     = (h.local_key != KS_NONE) != (h.layer_key != KS_NONE);
             auto       blend_into  = [&](f4(&D)[P]) {
                 if (FULL && op.blend_mode != 0) { /* a layer temporary composited with its blend mode */
-                    static_for<0, P>([&](auto I) {
-                        constexpr int i    = decltype(I)::value;
-                        const float   lkey = h.local_key == KS_KEY1 ? K1[i] : K0[i];
-                        const float   ykey = h.layer_key == KS_KEY1 ? K1[i] : K0[i];
-                        const f4      r    = shade_blend<true>(op, col[i], lkey, ykey, D[i]);
-                        D[i] = f4{quantize<BITS>(r.x), quantize<BITS>(r.y), quantize<BITS>(r.z), quantize<BITS>(r.w)};
-                    });
+                    shade_blend_mode4<BITS>(BlendArgs{h.flags, h.local_key, h.layer_key, h.opacity, op.blend_mode}, col, D, K0, K1);
                 } else if (simple)
                     blend_rgba4<BITS, 0>(h, col, D, K0, K1);
                 else if (plain_keyer && one_key)

@@ -17,7 +17,7 @@ def stack(kind, bits):
          # general-kernel paths: scaled (axis-aligned), rotated, perspective, unit-scale with a blend mode
          "g_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]), "g_rot": dict(opacity=0.8, angle=0.05),
          "g_pers": dict(opacity=0.8, pers_ul=[0.02, 0.01], pers_lr=[0.98, 0.99]),
-         "g_blend": dict(opacity=0.8, blend_mode="screen"), "g_bgra_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
+         "g_blend": dict(opacity=0.8, blend_mode=os.environ.get("PROBE_BLEND", "screen")), "g_bgra_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
          "g_unit": dict(opacity=0.8, fill_translation=[1.0 / W, 0.0])}[kind]
     ops = []
     for i in range(NL):
@@ -26,6 +26,9 @@ def stack(kind, bits):
     return S.scene("%s_%d" % (kind, bits), W, H, ops, bits=bits)
 
 which = os.environ.get("PROBE", "plain,key,chroma,levels,bgra").split(",")
+if os.environ.get("PROBE_FORCE_GENERAL"):
+    A.lib().cghip_debug_force_general_kernel(1)
+BLEND = os.environ.get("PROBE_BLEND", "screen")
 for bits in [int(b) for b in os.environ.get("PROBE_BITS", "16,8").split(",")]:
     for kind in which:
         sc = stack(kind, bits)
