@@ -47,6 +47,9 @@ void cghip_debug_generic_sampling(int on);
 void cghip_debug_pad_lds(int bytes);
 /* Rows (= waves) per workgroup of the 4-pixels-per-lane kernel, 1..4 (default 4): launch-shape experiments. */
 void cghip_debug_fast_rows(int rows);
+/* Large launches of the 4-pixels-per-lane kernel number their tiles so that neighbouring tiles share an XCD's L2
+ * (cghip_kernels.hip: xcd_block); on = tiles in dispatch order as in small launches, to measure the difference. */
+void cghip_debug_plain_tiles(int on);
 
 #ifdef __cplusplus
 }

@@ -969,6 +969,36 @@ DEV void store_key(void* buf, size_t idx, float k)
         ((uint16_t*)buf)[idx] = (uint16_t)to_code<16>(k);
 }
 
+/* Which tile of the frame this workgroup composites. Workgroups are dealt round-robin over the 8 XCDs in dispatch
+ * order (blocks b and b + 8 share one, MI355X_MICROARCH.md), each XCD with its own L2. Numbering tiles in that order
+ * puts horizontally adjacent tiles on different XCDs, and every cache line two tiles share (the 4:2:x neighbour
+ * texels, the halves of a 128-byte line) is then fetched from HBM once per XCD: the headline frame read 1.35 times
+ * its source bytes. Large launches (sp.nbx != 0) are therefore one-dimensional and hand out tiles in chunks of
+ * XCD_ROWS whole rows of tiles: chunk c goes to XCD c % 8, which walks it in row-major order (FETCH_SIZE 357 -> 243 MB
+ * per launch, time unchanged: the kernel is bound by the vector ALU). Measured alternatives: one contiguous band of
+ * the frame per XCD fetches the same and is 1 % faster on full-screen stacks, but draws that cover part of the frame
+ * then load the XCDs unevenly (config 2: +14 %); a (8 * tiles per row, XCD_ROWS, chunks) grid needs no divisions but
+ * ran 7 % slower. Small launches keep the plain two-dimensional numbering: their few MB sit in the Infinity Cache and
+ * the renumbering's two scalar divisions and padding workgroups showed (config 1: +7 %), and so does the general
+ * kernel, whose draws rarely cover whole rows. Pure renumbering: placement is never relied on. */
+constexpr unsigned XCD_ROWS = 4;
+DEV bool xcd_block(const KSpill& sp, unsigned& bx, unsigned& by)
+{
+    if (sp.nbx == 0) {
+        bx = blockIdx.x, by = blockIdx.y;
+        return true;
+    }
+    const unsigned nb = (unsigned)sp.nbx * (unsigned)sp.nby, C = (unsigned)sp.nbx * XCD_ROWS;
+    const unsigned L = blockIdx.x, j = L >> 3; /* j: position in this XCD's sequence */
+    const unsigned c = j / C, within = j - c * C;
+    const unsigned id = (c * 8u + (L & 7u)) * C + within;
+    if (id >= nb)
+        return false;
+    by = id / (unsigned)sp.nbx;
+    bx = id - by * (unsigned)sp.nbx;
+    return true;
+}
+
 /* General compositor: one output pixel per lane (one wave = 64 consecutive pixels of a row, one
  * workgroup = 4 rows). FULL = false drops the two extra RGBA surfaces (layer / mix temporaries) from the
  * register file: the host picks it when the frame has only normal-blend, non-mix layers. Surfaces are
@@ -979,10 +1009,13 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int y    = __builtin_amdgcn_readfirstlane(sp.gy0 + blockIdx.y * 4 + wave); /* wave-uniform: keep it scalar */
+    unsigned  bx, by;
+    if (!xcd_block(sp, bx, by))
+        return;
+    const int y = __builtin_amdgcn_readfirstlane(sp.gy0 + (int)by * 4 + wave); /* wave-uniform: keep it scalar */
     if (y >= H)
         return;
-    const int x = sp.gx0 + blockIdx.x * 64 + lane;
+    const int x = sp.gx0 + (int)bx * 64 + lane;
 
     f4    s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     float k0 = 0.0f, k1 = 0.0f;
@@ -1442,10 +1475,13 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
     constexpr int P    = 4;
     const int     lane = threadIdx.x & 63;
     const int     wave = threadIdx.x >> 6;
-    const int     y    = __builtin_amdgcn_readfirstlane(blockIdx.y * (blockDim.x >> 6) + wave); /* wave-uniform: keep it scalar */
+    unsigned      bx, by;
+    if (!xcd_block(sp, bx, by))
+        return;
+    const int y = __builtin_amdgcn_readfirstlane((int)by * (int)(blockDim.x >> 6) + wave); /* wave-uniform: keep it scalar */
     if (y >= H)
         return;
-    const int px0 = blockIdx.x * 64 * P + lane * P;
+    const int px0 = (int)bx * 64 * P + lane * P;
 
     f4    S[P], S1[P], S2[P];
     float K0[P], K1[P];
@@ -1619,6 +1655,9 @@ __global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restric
 
 /* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
 
+constexpr unsigned XCD_MIN_TILES = 4096; /* 1080p is 2160 tiles of the 4-pixels-per-lane kernel, 2160p 8100 */
+static int g_plain_tiles   = 0;
+extern "C" void cghip_debug_plain_tiles(int on) { g_plain_tiles = on; } /* measurements: tiles in dispatch order */
 static int g_pad_lds       = 0;
 static unsigned g_fast_rows = 4;
 extern "C" void cghip_debug_fast_rows(int rows) { g_fast_rows = rows >= 1 && rows <= 4 ? (unsigned)rows : 4u; }
@@ -1632,14 +1671,23 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
 {
     if (gw <= 0 || gh <= 0 || sp->gx0 < 0 || sp->gy0 < 0 || sp->gx0 + gw > W || sp->gy0 + gh > H)
         return hipErrorInvalidValue;
-    const KSpill s = *sp;
-    dim3         block(256);
+    KSpill s = *sp;
+    dim3   block(256);
+    auto   tiles = [&s](unsigned nbx, unsigned nby, bool by_xcd) { /* see xcd_block */
+        s.nbx = s.nby = 0;
+        if (!by_xcd)
+            return dim3(nbx, nby);
+        s.nbx = (int32_t)nbx, s.nby = (int32_t)nby;
+        const unsigned C = nbx * XCD_ROWS, chunks = (nbx * nby + C - 1) / C; /* whole chunks, as many on every XCD */
+        return dim3((chunks + 7u) / 8u * 8u * C);
+    };
     if (fast) {
         if (s.gx0 != 0 || s.gy0 != 0)
             return hipErrorInvalidValue; /* the 4-pixels-per-lane kernel always covers the frame */
         const unsigned rows = g_fast_rows; /* rows (= waves) per workgroup */
         block = dim3(64 * rows);
-        dim3 grid((unsigned)((gw + 255) / 256), (unsigned)((gh + rows - 1) / rows));
+        const unsigned nbx = (unsigned)((gw + 255) / 256), nby = (unsigned)((gh + rows - 1) / rows);
+        const dim3     grid = tiles(nbx, nby, nbx * nby >= XCD_MIN_TILES && !g_plain_tiles);
         if (bits == 8 && !full)
             hipLaunchKernelGGL((cghip_composite_fast<8, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (bits == 8)
@@ -1650,7 +1698,7 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
             hipLaunchKernelGGL((cghip_composite_fast<16, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         return hipGetLastError();
     }
-    dim3 grid((unsigned)((gw + 63) / 64), (unsigned)((gh + 3) / 4));
+    const dim3 grid = tiles((unsigned)((gw + 63) / 64), (unsigned)((gh + 3) / 4), false);
     if (bits == 8) {
         if (full)
             hipLaunchKernelGGL((cghip_composite<8, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);

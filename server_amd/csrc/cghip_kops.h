@@ -76,6 +76,7 @@ struct KSpill {
     uint32_t load_mask;  /* surfaces to read before the first op */
     uint32_t store_mask; /* surfaces to write after the last op */
     int32_t  gx0, gy0;
+    int32_t  nbx, nby;   /* workgroups per row of the launch and rows of workgroups (set by the launcher, see xcd_block) */
 };
 
 struct KPlane {

@@ -250,6 +250,27 @@ def test_full_size_properties(mixer):
     assert np.array_equal(c, d)
 
 
+@pytest.mark.parametrize("W,H", [(3840, 2160), (4100, 2050)])
+def test_tile_numbering_by_xcd_is_a_pure_renumbering(mixer, W, H):
+    """Large launches of the 4-pixels-per-lane kernel hand out their tiles in chunks per XCD (cghip_kernels.hip:
+    xcd_block). Every tile must still be composited exactly once: the frame equals the one rendered with tiles in
+    dispatch order, at a size whose tile count fills whole chunks and at one that leaves padding workgroups."""
+    import server_amd as A
+    L = A.lib()
+    cache = {}
+    sc = S.scene("xcd", W, H, [S.layer(S.ycbcr(W, H, "422", "video", 910, bits=16), opacity=0.9),
+                               S.layer(S.ycbcr(W, H, "420", "video", 911, bits=16), is_key=1),
+                               S.layer(S.bgra(W, H, "premul", 912, bits=16), opacity=0.7,
+                                       crop_ul=[0.25, 0.3], crop_lr=[0.75, 0.8])], bits=16)
+    a = S.run_product(sc, mixer=mixer, planes_cache=cache)
+    L.cghip_debug_plain_tiles(1)
+    try:
+        b = S.run_product(sc, mixer=mixer, planes_cache=cache)
+    finally:
+        L.cghip_debug_plain_tiles(0)
+    assert a.any() and np.array_equal(a, b)
+
+
 def test_routed_frame_is_peer_copied_once_per_device(mixer):
     """SURVEY 8f rank 1 (route_producer.cpp:40-126): a frame made by one channel's frame factory and visited by a mixer
     on another device is copied device-to-device once per destination device, however many layers and ticks show it,
