@@ -271,6 +271,56 @@ def test_tile_numbering_by_xcd_is_a_pure_renumbering(mixer, W, H):
     assert a.any() and np.array_equal(a, b)
 
 
+def test_producer_threads_create_frames_while_the_channel_renders(mixer):
+    """The threading contract of the boundary: create_frame + commit come from any producer thread,
+    concurrently (frame_factory, video_channel.cpp:267); push / visit / pop / render only from the channel thread.
+    Six producer threads create 20 frames each (pinned buffer from the pool, copy, upload on the device's upload
+    stream) while the channel thread keeps compositing; afterwards every frame, drawn alone, must give back its own
+    bytes (an opaque-or-not premultiplied BGRA layer over the empty frame is the identity), and the pools must not
+    have lost or duplicated a block."""
+    import threading
+    import server_amd as A
+    W, H, T, N = 320, 96, 6, 20
+    srcs = [[S.make_plane(W, H, 4, "premul", 2000 + t * N + i) for i in range(N)] for t in range(T)]
+    frames = [[None] * N for _ in range(T)]
+    errors = []
+
+    def producer(t):
+        try:
+            for i in range(N):
+                frames[t][i] = mixer.create_frame("bgra", [srcs[t][i]])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    busy = S.scene("busy", 640, 360, [S.layer(S.ycbcr(640, 360, "420", "video", 77), opacity=0.8),
+                                      S.layer(S.bgra(640, 360, "premul", 78), opacity=0.5, blend_mode="screen")])
+    first = S.run_product(busy, mixer=mixer)
+    threads = [threading.Thread(target=producer, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    renders = 0
+    while any(th.is_alive() for th in threads) or renders < 3:
+        assert np.array_equal(S.run_product(busy, mixer=mixer), first)
+        renders += 1
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    ident = A.default_transform(layer_depth=1)  # core::mixer opens a layer per stage frame (mixer.cpp:66)
+    for t in range(T):
+        for i in range(N):
+            mixer.push(ident)
+            mixer.visit_frame(frames[t][i])
+            mixer.pop()
+            out = mixer.render(W, H)
+            assert np.array_equal(out, srcs[t][i]), (t, i)
+    before = mixer.device_info()
+    for t in range(T):
+        for i in range(N):
+            mixer.destroy_frame(frames[t][i])
+    after = mixer.device_info()
+    assert before["planes_live"] - after["planes_live"] == T * N
+
+
 def test_routed_frame_is_peer_copied_once_per_device(mixer):
     """SURVEY 8f rank 1 (route_producer.cpp:40-126): a frame made by one channel's frame factory and visited by a mixer
     on another device is copied device-to-device once per destination device, however many layers and ticks show it,
