@@ -64,6 +64,7 @@ struct cghip_plane {
     size_t           bytes    = 0;
     int              width = 0, height = 0, channels = 0, bits = 0;
     hipEvent_t       ready    = nullptr; /* recorded after the upload / peer copy */
+    std::atomic<bool> ready_seen{false}; /* the event was once found complete: later frames need not wait on it */
     std::atomic<int> refs{1};
     bool             stub = false; /* planner tests: no device memory behind it */
     cghip_plane*     parent = nullptr; /* cghip_plane_view: dptr and ready belong to the parent, which is retained */
@@ -74,6 +75,7 @@ struct cghip_mixer {
     cghip_device* dev        = nullptr;
     int           channel_id = 0;
     hipStream_t   stream     = nullptr; /* compositor + readback of this channel */
+    hipStream_t   ops_stream = nullptr; /* uploads a frame's op list while the previous frame is still compositing */
 };
 
 struct cghip_ticket {
@@ -85,7 +87,7 @@ struct cghip_ticket {
     void*                     d_ops = nullptr;
     void*                     h_ops = nullptr; /* pinned staging of the op list */
     size_t                    ops_bytes = 0;
-    hipEvent_t                ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    hipEvent_t                ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr, ev_ops = nullptr;
     int                       launches = 0;
     void*                     spill[4] = {nullptr, nullptr, nullptr, nullptr}; /* RGBA1, RGBA2, KEY0, KEY1 between launches */
     size_t                    spill_bytes[4] = {0, 0, 0, 0};

@@ -415,6 +415,11 @@ int cghip_mixer_create(cghip_device* dev, int channel_id, cghip_mixer** out)
     cghip_mixer* m = new cghip_mixer();
     m->dev = dev, m->channel_id = channel_id;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        e = hipStreamCreateWithFlags(&m->ops_stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            (void)hipStreamDestroy(m->stream);
+    }
     if (e != hipSuccess) {
         delete m;
         return fail_hip(e, "hipStreamCreateWithFlags");
@@ -429,7 +434,9 @@ int cghip_mixer_destroy(cghip_mixer* mixer)
     if (!mixer)
         return CGHIP_OK;
     (void)hipSetDevice(mixer->dev->gpu);
+    (void)hipStreamSynchronize(mixer->ops_stream);
     (void)hipStreamSynchronize(mixer->stream);
+    (void)hipStreamDestroy(mixer->ops_stream);
     (void)hipStreamDestroy(mixer->stream);
     mixer->dev->mixers--;
     delete mixer;
@@ -442,9 +449,12 @@ static void ticket_free(cghip_ticket* t)
     if (t->ev_done) {
         (void)hipEventSynchronize(t->ev_done);
         (void)hipEventDestroy(t->ev_done);
+    } else if (t->ev_stop) {
+        (void)hipEventSynchronize(t->ev_stop);
     }
     if (t->ev_start) (void)hipEventDestroy(t->ev_start);
     if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
+    if (t->ev_ops) (void)hipEventDestroy(t->ev_ops);
     dev->dev_free(t->d_out, t->out_bytes);
     dev->dev_free(t->d_ops, t->ops_bytes);
     for (int i = 0; i < 4; ++i)
@@ -499,18 +509,39 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     T_TRY(dev->pinned_alloc(t->ops_bytes, &t->h_ops));
     T_HIP(hipEventCreate(&t->ev_start));
     T_HIP(hipEventCreate(&t->ev_stop));
-    T_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+    if (flags & CGHIP_RENDER_READBACK) /* without a readback the frame is done when its last launch is: ev_stop */
+        T_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
 
-    /* the frame keeps its source planes alive and waits for their uploads (device.cpp:242-262 futures) */
+    /* The op list goes up on a stream of its own, so that it travels while the previous frame of this channel is
+       still compositing; on the compositor's stream the copy sat between two launches. The ticket's buffers are its
+       own (or from the pool, whose previous user is done), so nothing else orders this copy. */
+    if (!plan.ops.empty()) {
+        std::memcpy(t->h_ops, plan.ops.data(), plan.ops.size() * sizeof(KOp));
+        T_HIP(hipEventCreateWithFlags(&t->ev_ops, hipEventDisableTiming));
+        T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, mixer->ops_stream));
+        T_HIP(hipEventRecord(t->ev_ops, mixer->ops_stream));
+    }
+    /* the frame keeps its source planes alive and waits for their uploads (device.cpp:242-262 futures). A still or a
+       routed frame is visited tick after tick: once its upload has been seen complete there is nothing to wait for,
+       and a 16-layer 4:2:2 frame no longer queues 48 event waits in front of its launch. */
     for (cghip_plane* p : plan.planes) {
         cghip_plane_retain(p);
         t->planes.push_back(p);
-        T_HIP(hipStreamWaitEvent(t->stream, p->ready, 0));
+        cghip_plane* root = p->parent ? p->parent : p; /* a view shares its parent's event */
+        if (root->ready_seen.load(std::memory_order_acquire))
+            continue;
+        const hipError_t q = hipEventQuery(root->ready);
+        if (q == hipSuccess) {
+            root->ready_seen.store(true, std::memory_order_release);
+            continue;
+        }
+        if (q != hipErrorNotReady)
+            T_HIP(q);
+        (void)hipGetLastError();
+        T_HIP(hipStreamWaitEvent(t->stream, root->ready, 0));
     }
-    if (!plan.ops.empty()) {
-        std::memcpy(t->h_ops, plan.ops.data(), plan.ops.size() * sizeof(KOp));
-        T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, t->stream));
-    }
+    if (t->ev_ops)
+        T_HIP(hipStreamWaitEvent(t->stream, t->ev_ops, 0));
     T_HIP(hipEventRecord(t->ev_start, t->stream));
     /* one launch per segment of the plan, in order on the mixer's stream; surfaces that are live across a cut travel
        through the frame buffer (RGBA0) and the ticket's spill buffers. An empty scene is one launch with zero ops
@@ -545,7 +576,8 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
             T_HIP(hipMemcpyAsync(t->h_out, t->d_out, t->out_bytes, hipMemcpyDeviceToHost, t->stream));
         }
     }
-    T_HIP(hipEventRecord(t->ev_done, t->stream));
+    if (t->ev_done) /* every event record is a packet the queue works through between two launches */
+        T_HIP(hipEventRecord(t->ev_done, t->stream));
 #undef T_TRY
 #undef T_HIP
     dev->frames_rendered++;
@@ -558,7 +590,7 @@ int cghip_ticket_wait(cghip_ticket* ticket, const uint8_t** data, size_t* size)
 {
     if (!ticket)
         return fail(CGHIP_ERR_INVALID, "ticket is null");
-    CGHIP_TRY_HIP(hipEventSynchronize(ticket->ev_done));
+    CGHIP_TRY_HIP(hipEventSynchronize(ticket->ev_done ? ticket->ev_done : ticket->ev_stop));
     if (data) {
         if (!ticket->h_out)
             return fail(CGHIP_ERR_INVALID, "frame was rendered without CGHIP_RENDER_READBACK");
