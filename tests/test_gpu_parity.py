@@ -271,6 +271,22 @@ def test_tile_numbering_by_xcd_is_a_pure_renumbering(mixer, W, H):
     assert a.any() and np.array_equal(a, b)
 
 
+def test_8k_frame_matches_oracle(mixer):
+    """Largest broadcast raster (7680x4320, 32 400 tiles of the 4-pixels-per-lane kernel, planes of 133 MB addressed with
+    32-bit byte offsets): bit-exact against the oracle like every other 8-bit frame. One layer is cropped at odd
+    columns (edge lanes), one is a scaled box (second launch, general kernel over its box only)."""
+    W, H = 7680, 4320
+    sc = S.scene("8k", W, H, [
+        S.layer(S.bgra(W, H, "premul", 950), opacity=0.9),
+        S.layer(S.ycbcr(W, H, "422", "video", 951), opacity=0.8, crop_ul=[0.1003, 0.2], crop_lr=[0.9001, 0.85]),
+        S.layer(S.ycbcr(W // 4, H // 4, "420", "video", 952), opacity=0.7, fill_scale=[0.3, 0.3], fill_translation=[0.6, 0.1]),
+    ])
+    got = S.run_product(sc, mixer=mixer)
+    ref = S.run_oracle(sc, "cpu")
+    st = S.diff_stats(got, ref)
+    assert got.any() and st["max"] == 0, st
+
+
 def test_producer_threads_create_frames_while_the_channel_renders(mixer):
     """The threading contract of the boundary: create_frame + commit come from any producer thread,
     concurrently (frame_factory, video_channel.cpp:267); push / visit / pop / render only from the channel thread.
