@@ -725,7 +725,15 @@ DEV f4 sel4(bool c, f4 a, f4 b) { return f4{c ? a.x : b.x, c ? a.y : b.y, c ? a.
 
 /* ---- straight-line bilinear bodies for the two common 8-bit layouts (KSampleClass) ---- */
 
-DEV int lerp8s(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); } /* == one byte of lerp8x4 */
+/* == one byte of lerp8x4. |b - a| and w fit in 9 bits, so the 24-bit multiply-add is exact; written out because the
+ * compiler only proves that for operands straight from a byte load and made the second-level lerp a 64-bit
+ * multiply-add (v_mad_u64_u32) */
+DEV int lerp8s(int a, int b, int w)
+{
+    int t;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(w), "v"(b - a), "s"(128));
+    return a + (t >> 8);
+}
 
 /* byte offsets of the four taps of a GL_LINEAR + CLAMP_TO_EDGE fetch at 24.8 fixed-point texel coordinates
  * (already shifted by half a texel), and the two 8-bit weights */
@@ -894,12 +902,16 @@ DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
     bool         in0 = true;
     float        s, t;
     if (!(h.flags & KF_RECT)) { /* which triangle covers the pixel centre, if any */
-        bool in1 = op.ntri > 1;
+        /* all six edge functions, then the tests: with short-circuit && every edge sat in a block of its own behind
+           its own scalar load and wait (six serial scalar-cache round trips per op and wave) */
+        double e0[3], e1[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            in0 = in0 && __builtin_fma(op.tri[0].e[k][0], dx, __builtin_fma(op.tri[0].e[k][1], dy, op.tri[0].e[k][2])) >= 0.0;
-            in1 = in1 && __builtin_fma(op.tri[1].e[k][0], dx, __builtin_fma(op.tri[1].e[k][1], dy, op.tri[1].e[k][2])) >= 0.0;
+            e0[k] = __builtin_fma(op.tri[0].e[k][0], dx, __builtin_fma(op.tri[0].e[k][1], dy, op.tri[0].e[k][2]));
+            e1[k] = __builtin_fma(op.tri[1].e[k][0], dx, __builtin_fma(op.tri[1].e[k][1], dy, op.tri[1].e[k][2]));
         }
+        in0            = (e0[0] >= 0.0) & (e0[1] >= 0.0) & (e0[2] >= 0.0);
+        const bool in1 = (op.ntri > 1) & (e1[0] >= 0.0) & (e1[1] >= 0.0) & (e1[2] >= 0.0);
         if (!in0 && !in1)
             return false;
     }

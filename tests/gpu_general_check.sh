@@ -1,0 +1,10 @@
+#!/bin/bash
+# parity, config times and the general-kernel probe after a change to cghip_composite (run through gpurun)
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1 || { echo "tests failed"; tail -20 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+timeout -k 10 200 python -u tests/gpu_config_times.py > gpurun_out/config_times.log 2>&1 || { echo "config times failed"; tail -5 gpurun_out/config_times.log; exit 1; }
+grep -v amdgpu.ids gpurun_out/config_times.log
+PROBE=g_rect,g_rot,g_pers,g_bgra_rect,g_unit PROBE_LAYERS=16 PROBE_SETTLE=100 timeout -k 10 300 python -u tests/gpu_probe.py > gpurun_out/probe_general.log 2>&1 || { echo "probe failed"; tail -5 gpurun_out/probe_general.log; exit 1; }
+grep -v amdgpu.ids gpurun_out/probe_general.log
