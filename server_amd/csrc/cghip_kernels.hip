@@ -1479,9 +1479,11 @@ DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
 
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
- * either keyer) and item draws into them. 151 VGPRs: three waves per SIMD. */
+ * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
+/* amdgpu_waves_per_eu(4): at least four waves per SIMD, i.e. at most 128 VGPRs. Left alone the FULL variant takes 149
+ * (three waves); with the bound it fits 128 without a spill. The variant without the temporaries (79) is not affected. */
 template <int BITS, bool FULL>
-__global__ __launch_bounds__(256) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* out, int W, int H,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* out, int W, int H,
                                                             int field_mode, KSpill sp)
 {
     constexpr int P    = 4;
