@@ -1480,11 +1480,8 @@ DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
-/* amdgpu_waves_per_eu(4): at least four waves per SIMD, i.e. at most 128 VGPRs. Left alone the FULL variant takes 149
- * (three waves); with the bound it fits 128 without a spill. The variant without the temporaries (79) is not affected. */
 template <int BITS, bool FULL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void cghip_composite_fast(const KOp* __restrict__ ops, int nops, void* out, int W, int H,
-                                                            int field_mode, KSpill sp)
+DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, const KSpill& sp)
 {
     constexpr int P    = 4;
     const int     lane = threadIdx.x & 63;
@@ -1667,6 +1664,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     }
 }
 
+/* The two variants as kernels of their own, each with its register bound (amdgpu_waves_per_eu(n): at least n waves
+ * per SIMD, i.e. at most 512 / n VGPRs). With the temporaries: left alone 149 VGPRs (three waves), bounded 128 without a
+ * spill (16 blend layers at 2160p 0.78 -> 0.65 ms). Without them: left alone 79 (six waves), bounded to seven waves 72
+ * with four registers spilled outside the hot bodies (LEAN_WAVES, measured below). */
+#ifndef LEAN_WAVES
+#define LEAN_WAVES 7
+#endif
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEAN_WAVES))) void cghip_composite_fast(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, false>(ops, nops, out, W, H, field_mode, sp);
+}
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void cghip_composite_fast_full(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, true>(ops, nops, out, W, H, field_mode, sp);
+}
+
 /* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
 
 constexpr unsigned XCD_MIN_TILES = 4096; /* 1080p is 2160 tiles of the 4-pixels-per-lane kernel, 2160p 8100 */
@@ -1703,13 +1720,13 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
         const unsigned nbx = (unsigned)((gw + 255) / 256), nby = (unsigned)((gh + rows - 1) / rows);
         const dim3     grid = tiles(nbx, nby, nbx * nby >= XCD_MIN_TILES && !g_plain_tiles);
         if (bits == 8 && !full)
-            hipLaunchKernelGGL((cghip_composite_fast<8, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (bits == 8)
-            hipLaunchKernelGGL((cghip_composite_fast<8, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            hipLaunchKernelGGL((cghip_composite_fast_full<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!full)
-            hipLaunchKernelGGL((cghip_composite_fast<16, false>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            hipLaunchKernelGGL((cghip_composite_fast<16>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else
-            hipLaunchKernelGGL((cghip_composite_fast<16, true>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            hipLaunchKernelGGL((cghip_composite_fast_full<16>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         return hipGetLastError();
     }
     const dim3 grid = tiles((unsigned)((gw + 63) / 64), (unsigned)((gh + 3) / 4), false);
