@@ -306,8 +306,8 @@ def main():
                 "channels_per_gpu": ncha, "frames_in_flight": 2, "settle_s": SETTLE_S, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "cghip_composite_fast<%d>" % scene["bits"] if args.workload in ("config3_16bit", "config3_8bit", "config1", "config4")
-                         else "cghip_composite<%d>" % scene["bits"],
+                         "kernel": {"config4": "cghip_composite_fast_full<%d>", "config2": "cghip_composite<%d>"}.get(
+                             args.workload, "cghip_composite_fast<%d>") % scene["bits"],
                          "avg_kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
             "cpu_baseline": cpu,
