@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--workload", default="config3_16bit", choices=sorted(WORKLOADS))
     ap.add_argument("--channels-per-gpu", type=int, default=1,
                     help="channels each rank drives on its GPU, one stream each (configs[3]: 32 channels over N GPUs)")
+    ap.add_argument("--settle", type=float, default=SETTLE_S,
+                    help="seconds of untimed load before the warmup steps (counter-collection passes use a short one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
@@ -240,7 +242,7 @@ def main():
     # 0.277). A channel composites for hours, so the sustained rate is the one to report. Untimed, before the W warmup
     # steps, reported as config.settle_s.
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < SETTLE_S:
+    while time.perf_counter() - t_settle < args.settle:
         run_steps_channels(chs, 20)
     run_steps_channels(chs, max(1, args.warmup))
     device_sync()
@@ -305,7 +307,7 @@ def main():
             "config": {"workload": "%s: %dx%d, %d layers, %d-bit out" % (
                 scene["name"], scene["width"], scene["height"],
                 sum(1 for o in scene["ops"] if o[0] == "visit"), scene["bits"]),
-                "channels_per_gpu": ncha, "frames_in_flight": 2, "settle_s": SETTLE_S, "parallelism": "channel-sharded x%d" % world},
+                "channels_per_gpu": ncha, "frames_in_flight": 2, "settle_s": args.settle, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {"config4": "cghip_composite_fast_full<%d>", "config2": "cghip_composite<%d>"}.get(

@@ -11,7 +11,7 @@ print("BENCH value %.1f fps  kernel %.3f ms  achieved %.0f GB/s frac %.3f" % (d[
 PY
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d gpurun_out/pmc -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> gpurun_out/pmc.err || { echo pmc failed; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d gpurun_out/pmc -o p -- python3 bench.py --settle 0.5 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2> gpurun_out/pmc.err || { echo pmc failed; exit 1; }
 python - <<'PY'
 import csv, collections
 agg=collections.defaultdict(list)

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for wl in config3_16bit config2; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_${wl}_$c
-    timeout -s KILL 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${wl}_$c -o p -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end > /dev/null 2> gpurun_out/pmc_${wl}_$c.err || { echo "pmc $wl $c failed"; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${wl}_$c -o p -- python3 bench.py --settle 0.5 --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end > /dev/null 2> gpurun_out/pmc_${wl}_$c.err || { echo "pmc $wl $c failed"; exit 1; }
   done
 done
 python3 - <<'PY'
