@@ -515,7 +515,10 @@ static void* new_temp(render_ctx* c, int w, int h, int stride)
     return t;
 }
 
-/* draw(target, source_buffer, blend_mode)  image_mixer.cpp:207-225 */
+/* draw(target, source_buffer, blend_mode)  image_mixer.cpp:207-225. The reference's parameter is a NAMED rvalue
+ * reference: `spl::make_shared_ptr(source_buffer)` (common/memory.h:633, by value) copies from it, so the caller's
+ * pointer is NOT reset. A layer's mix texture therefore stays set once created: it is composited again in front of
+ * every later plain item (:197) and at the end of the layer (:138/:150), and later mix items accumulate into it. */
 static void draw_buffer(render_ctx* c, void* target, void** source_buffer, int blend_mode)
 {
     if (!*source_buffer)
@@ -539,7 +542,6 @@ static void draw_buffer(render_ctx* c, void* target, void** source_buffer, int b
     kp.aspect_ratio = 1.0; /* draw_params default :51 */
     kp.field_mode   = c->fmt->field_mode;
     kernel_draw(c->m, &kp);
-    *source_buffer = NULL; /* moved-from */
 }
 
 /* draw(target, item, layer_key, local_key, local_mix)  image_mixer.cpp:156-205 */

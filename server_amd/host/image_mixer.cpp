@@ -299,7 +299,10 @@ class draw_recorder
         }
     }
 
-    void draw(int target, int& source_buffer, core::blend_mode blend_mode) /* :207-225 */
+    /* :207-225. `source_buffer` is a named rvalue reference in the reference and spl::make_shared_ptr takes its
+       argument by value (common/memory.h:633): the caller's texture is copied, never moved from. A layer's mix texture
+       so stays set: it is composited again before every later plain item (:197) and at the layer's end (:138/:150). */
+    void draw(int target, const int& source_buffer, core::blend_mode blend_mode)
     {
         if (source_buffer == none)
             return;
@@ -320,7 +323,6 @@ class draw_recorder
             d.coords[i] = cghip_coord{g[i].vertex_x, g[i].vertex_y, g[i].texture_x, g[i].texture_y, g[i].texture_r, g[i].texture_q};
         d.aspect_ratio = 1.0;
         out_.push_back(std::move(dc));
-        source_buffer = none;
     }
 
     const core::video_format_desc& format_desc_;

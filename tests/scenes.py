@@ -186,6 +186,26 @@ def small_scenes():
                      ("push", dict(is_mix=1, opacity=0.4)), ("visit", bgra(W, H, "premul", 48)), ("pop",),
                      ("push", dict(is_mix=1, opacity=0.6)), ("visit", bgra(W, H, "premul", 49)), ("pop",),
                      ("pop",)]]))
+    # a layer's mix texture is never reset (image_mixer.cpp:207-225 copies from the named rvalue reference): it is
+    # composited again before every later plain item and at the layer's end, and later mix items add to it
+    S.append(scene("mix_then_plain_item", W, H,
+                   [bg, [("push", dict(layer_depth=1)),
+                         ("push", dict(is_mix=1, opacity=0.4)), ("visit", bgra(W, H, "premul", 53)), ("pop",),
+                         ("push", dict(opacity=0.5, fill_scale=[0.5, 0.5], fill_translation=[0.25, 0.25])),
+                         ("visit", bgra(W, H, "premul", 54)), ("pop",),
+                         ("pop",)]]))
+    S.append(scene("mix_plain_mix_plain", W, H,
+                   [bg, [("push", dict(layer_depth=1)),
+                         ("push", dict(is_mix=1, opacity=0.3)), ("visit", bgra(W, H, "premul", 55)), ("pop",),
+                         ("push", dict(opacity=0.6)), ("visit", ycbcr(W, H, "422", "video", 56)), ("pop",),
+                         ("push", dict(is_mix=1, opacity=0.2)), ("visit", bgra(W, H, "premul", 57)), ("pop",),
+                         ("push", dict(opacity=0.3)), ("visit", bgra(W, H, "premul", 58)), ("pop",),
+                         ("pop",)]]))
+    S.append(scene("mix_then_plain_in_blend_layer", W, H,
+                   [bg, [("push", dict(layer_depth=1, blend_mode="screen")),
+                         ("push", dict(is_mix=1, opacity=0.4)), ("visit", bgra(W, H, "premul", 59)), ("pop",),
+                         ("push", dict(opacity=0.5)), ("visit", bgra(W, H, "premul", 62)), ("pop",),
+                         ("pop",)]]))
     S.append(scene("sublayers", W, H,
                    [bg, [("push", dict(layer_depth=1, opacity=0.9)),
                          ("push", dict(layer_depth=1, blend_mode="add", fill_scale=[0.5, 0.5])), ("visit", bgra(W, H, "premul", 50)), ("pop",),
@@ -230,6 +250,15 @@ def sixteen_bit_scenes():
                    [bg, layer(ycbcr(48, 32, "422", "video", 78, bits=16), fill_scale=[0.8, 0.7], fill_translation=[0.1, 0.13])], bits=16))
     S.append(scene("b16_screen_blend", W, H, [bg, layer(ycbcr(W, H, "422", "video", 79, bits=16), blend_mode="screen", opacity=0.8)], bits=16))
     S.append(scene("b16_from_8bit_sources", W, H, [bg, layer(bgra(W, H, "premul", 80), opacity=0.9)], bits=16))
+    # 1:1 sources a small fraction of a texel off the pixel grid: a 16-bit source is filtered with fp32 weights, so
+    # 1e-3 texel is worth up to ~65 LSB16 on noise and must NOT be snapped to the unit-scale class (8-bit sources
+    # have 1/256 weight steps and may be)
+    for tag, frac in (("5e-4", 0.0005), ("5e-3", 0.005), ("5e-2", 0.05), ("2e-1", 0.2)):
+        S.append(scene("b16_near_unit_" + tag, W, H,
+                       [bg, layer(ycbcr(W, H, "422", "noise", 81, bits=16), opacity=0.9,
+                                  fill_translation=[(4 + frac) / W, (2 + frac) / H]),
+                        layer(bgra(W, H, "noise", 82, bits=16), opacity=0.5,
+                              fill_translation=[-(8 + frac) / W, (1 - frac) / H])], bits=16))
     return S
 
 

@@ -396,3 +396,35 @@ def test_fuzz_scenes_cut_at_every_class_change_hand_surfaces_over_correctly(bits
     finally:
         K.set_cut_policy()
     assert n_cut > 60 and n_spill > 20, (n_cut, n_spill)
+
+
+def _draw_sequence(sc):
+    """(kind, target slot, source slot) per recorded draw: 'S' = composite of a temporary, 'K'/'M'/'P' = key / mix /
+    plain item."""
+    draws, _surf, _ops, _full = product_plan(sc)
+    seq = []
+    for d in draws:
+        if d.source_surface >= 0:
+            seq.append(("S", d.target, d.source_surface))
+        else:
+            t = d.transform
+            seq.append(("K" if t.is_key else "M" if t.is_mix else "P", d.target, -1))
+    return seq
+
+
+def test_mix_texture_is_never_reset_within_a_layer():
+    """image_mixer.cpp:207-225 binds local_mix_texture to a NAMED rvalue reference and copies from it
+    (common/memory.h:633), so the mix texture survives its composite: it is composited again in front of every later
+    plain item (:197) and at the layer's end (:150), and later mix items draw into the SAME texture."""
+    by_name = {s["name"]: s for s in S.small_scenes()}
+    # [mix A, plain B]: composite, B, composite again
+    assert _draw_sequence(by_name["mix_then_plain_item"])[1:] == [("M", 1, -1), ("S", 0, 1), ("P", 0, -1), ("S", 0, 1)]
+    # [mix A, plain B, mix C, plain D]: C lands in the same texture (slot 1), which is composited three times
+    assert _draw_sequence(by_name["mix_plain_mix_plain"])[1:] == [
+        ("M", 1, -1), ("S", 0, 1), ("P", 0, -1), ("M", 1, -1), ("S", 0, 1), ("P", 0, -1), ("S", 0, 1)]
+    # inside a blend-mode layer the composites go to the layer texture (slot 1), the mix texture is slot 2
+    assert _draw_sequence(by_name["mix_then_plain_in_blend_layer"])[1:] == [
+        ("M", 2, -1), ("S", 1, 2), ("P", 1, -1), ("S", 1, 2), ("S", 0, 1)]
+    # and the oracle's own log agrees on the number of GL draws
+    for name, n in (("mix_then_plain_item", 5), ("mix_plain_mix_plain", 8), ("mix_then_plain_in_blend_layer", 6)):
+        assert len(oracle_log(by_name[name])) == n, name
