@@ -131,6 +131,9 @@ def lib():
         L.ref_geometry_default_vflip.argtypes = [Coord * 4]
         L.cpuref_backend.restype = C.POINTER(Backend)
         L.cpuref_set_threads.argtypes = [C.c_int]
+        L.cpuref_set_background_bilinear.argtypes = [C.c_int]
+        L.cpuref_set_fetch_delta.argtypes = [C.c_float] * 4
+        L.cpuref_set_snap_fetch.argtypes = [C.c_int]
         _lib = L
     return _lib
 

@@ -87,6 +87,24 @@ static void texel_int(const cpu_tex* t, int x, int y, int out[4])
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* Test switch (tests/parity16.py): a constant (r,g,b,a) added to the result of every fetch from a 16-bit texture
+ * (source planes, keys, temporaries, the background), far below one LSB16 (1e-6 is 0.07 LSB16). It stands for ANY
+ * neighbour contribution of the size a float filter weight's last bits carry, whatever the traversal order: a pixel
+ * whose output moves by whole LSBs under it is one whose colour is decided by that noise (a blend mode dividing by an
+ * alpha that is zero but for the noise, shader.frag:427-428), not by the inputs. */
+static float g_fetch_delta[4] = {0, 0, 0, 0};
+void cpuref_set_fetch_delta(float r, float g, float b, float a)
+{
+    g_fetch_delta[0] = r, g_fetch_delta[1] = g, g_fetch_delta[2] = b, g_fetch_delta[3] = a;
+}
+
+/* Test switch (tests/parity16.py): 16-bit filter weights within 5e-4 of a multiple of 1/8 take that value (0 for a 1:1
+ * fetch, 1/4 and 3/4 for the half-width chroma planes of a 1:1 4:2:x layer), i.e. the float noise a weight carries
+ * for such mappings (from a few 1e-6 at 100 pixels width to 1.2e-4 at 3840) is removed. Comparing both settings shows the pixels of a scene whose
+ * output is decided by that noise. Never on in a parity comparison. */
+static int g_snap_fetch = 0;
+void       cpuref_set_snap_fetch(int on) { g_snap_fetch = on; }
+
 /*
  * texture(sampler2D, coords): GL_LINEAR, CLAMP_TO_EDGE, single level.
  * 8-bit UNORM textures follow llvmpipe's fixed-point path: coordinate -> 24.8 fixed point, minus half a
@@ -129,6 +147,13 @@ static v4 sample(const cpu_tex* t, float s, float tt)
         float v  = tt * (float)t->h - 0.5f;
         float fx = floorf(u), fy = floorf(v);
         float wx = u - fx, wy = v - fy;
+        if (g_snap_fetch) {
+            const float sx = rintf(wx * 8.0f) * 0.125f, sy = rintf(wy * 8.0f) * 0.125f;
+            if (fabsf(wx - sx) < 5e-4f) wx = sx;
+            if (fabsf(wy - sy) < 5e-4f) wy = sy;
+            if (wx == 1.0f) fx += 1.0f, wx = 0.0f;
+            if (wy == 1.0f) fy += 1.0f, wy = 0.0f;
+        }
         int   x0 = (int)fx, y0 = (int)fy;
         int   x1 = clampi(x0 + 1, 0, t->w - 1), y1 = clampi(y0 + 1, 0, t->h - 1);
         x0 = clampi(x0, 0, t->w - 1);
@@ -147,7 +172,8 @@ static v4 sample(const cpu_tex* t, float s, float tt)
             float b = f10 + wx * (f11 - f10);
             o[k]    = a + wy * (b - a);
         }
-        r.x = o[0], r.y = o[1], r.z = o[2], r.w = o[3];
+        r.x = o[0] + g_fetch_delta[0], r.y = o[1] + g_fetch_delta[1], r.z = o[2] + g_fetch_delta[2];
+        r.w = o[3] + g_fetch_delta[3];
     }
     return r;
 }
@@ -162,16 +188,24 @@ static v4 sample(const cpu_tex* t, float s, float tt)
  * The restatement takes the defined part: the pixel's own texel. (Found by tests/test_fuzz.py: with the bilinear
  * fetch this file was 1 LSB16 off llvmpipe AND the HIP mixer on ~0.4 % of samples of a plain stretched layer.)
  */
+static int g_bg_bilinear = 0;
+/* Test switch (tests/parity16.py, tests/test_oracle_golden.py): 1 = fetch the background with the bilinear float
+ * filter in scanline order, i.e. mix ~1e-6 of the left / upper neighbours this draw has just written into a 16-bit
+ * background. That is one of the possible outcomes of the undefined read; comparing both settings with llvmpipe
+ * shows which pixels of a scene depend on it. */
+void cpuref_set_background_bilinear(int on) { g_bg_bilinear = on; }
+
 static v4 sample_own_pixel(const cpu_tex* t, float s, float tt)
 {
-    if (t->bits == 8)
+    if (t->bits == 8 || g_bg_bilinear)
         return sample(t, s, tt);
     int x = clampi((int)floorf(s * (float)t->w), 0, t->w - 1);
     int y = clampi((int)floorf(tt * (float)t->h), 0, t->h - 1);
     int c[4];
     texel_int(t, x, y, c);
     const float sc = 1.0f / 65535.0f;
-    return (v4){(float)c[0] * sc, (float)c[1] * sc, (float)c[2] * sc, (float)c[3] * sc};
+    return (v4){(float)c[0] * sc + g_fetch_delta[0], (float)c[1] * sc + g_fetch_delta[1],
+                (float)c[2] * sc + g_fetch_delta[2], (float)c[3] * sc + g_fetch_delta[3]};
 }
 
 /* ------------------------------------------------------------------ GLSL helpers */

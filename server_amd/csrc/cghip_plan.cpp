@@ -459,7 +459,16 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
         auto v = [&](double x, double y) { return (m.a[1][0] + m.a[1][1] * x + m.a[1][2] * y) * h0 - 0.5; };
         const double xa = op.x0, xb = op.x1 - 1, ya = op.y0, yb = op.y1 - 1;
         const double du = u(xa, ya) - xa, dv = v(xa, ya) - ya;
-        const double tol = 1e-3;
+        /* How far from the texel grid a source may sit and still be addressed by texel index. 8-bit planes are
+           filtered with 8-bit weights, rint(coordinate * 256) & 255: below 1/512 texel the weight is 0 and the result
+           IS the texel, so 1e-3 is exact. 16-bit planes are filtered with fp32 weights (
+           llvmpipe's float path): a weight w mixes in w * (neighbour - texel), up to w * 65535 LSB16, so the offset
+           has to be below 2^-17 texel to stay under half an LSB16 on any content; anything further off takes the
+           sampled path with the same fp32 weights as the reference pipeline. */
+        bool wide = false;
+        for (int n = 0; n < op.nplanes; ++n)
+            wide = wide || op.planes[n].bits > 8;
+        const double tol = wide ? 1.0 / 131072.0 : 1e-3;
         const bool   ok  = std::fabs(du - std::round(du)) < tol && std::fabs(dv - std::round(dv)) < tol &&
                         std::fabs((u(xb, yb) - xb) - du) < tol && std::fabs((v(xb, yb) - yb) - dv) < tol &&
                         std::fabs((u(xb, ya) - xb) - du) < tol && std::fabs((v(xa, yb) - yb) - dv) < tol &&

@@ -24,3 +24,15 @@ def oracle_lib():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """16-bit parity numbers collected by tests/parity16.py during a GPU session (worst case per scene or scene family)."""
+    import json
+    import parity16
+    if not parity16.REPORT:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity16_report.json"), "w") as f:
+        json.dump(parity16.REPORT, f, indent=1, sort_keys=True)

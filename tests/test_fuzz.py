@@ -3,6 +3,7 @@ shader; (GPU) the HIP mixer against the oracle. Same seeded scenes (tests/fuzz_s
 import numpy as np
 import pytest
 
+import parity16 as P16
 import scenes as S
 from fuzz_scenes import fuzz_scene
 
@@ -37,13 +38,71 @@ def test_oracle_matches_llvmpipe_on_random_scenes(seed):
     assert st["gt0"] <= 2e-3 and st["gt1"] <= 6e-4, st
 
 
+def _gl_field(sc, a, b):
+    if sc["field_mode"]:  # the field mask is this project's extension: GL draws every row
+        first = sc["field_mode"] - 1
+        assert not a[1 - first::2].any()
+        b = b.copy()
+        b[1 - first::2] = 0
+    return b
+
+
+def test_oracle_matches_llvmpipe_on_random_16bit_scenes():
+    """The same pin for the 16-bit extension (R16 / RGBA16 textures under the unchanged shader), with a MAXIMUM: the
+    restatement is within +-2 LSB16 of llvmpipe at every pixel that is not an amplifying pixel of the scene
+    (tests/parity16.py) except for a bounded number of single pixels where the two rasterisers decide a discrete
+    outcome differently (coverage of a rotated edge, a texel boundary, a chroma-key threshold - the same classes as in
+    the 8-bit test above) or a gain of 2..3 (contrast, levels) turns 1 LSB16 of filter noise into 3. Measured over these
+    200 scenes: 74 have pixels beyond +-2, all of them amplifying pixels in 54; the other 20 leave 1..10 pixels
+    unexplained (at most 2.7e-3 of a scene). One scene needs the tier-2 probes."""
+    if not _gl():
+        pytest.skip("llvmpipe harness not available here")
+    beyond = unexplained = 0
+    for seed in range(N_CPU):
+        sc = fuzz_scene(seed, 16)
+        cache = {}
+        a = S.run_oracle(sc, "cpu", cache)
+        b = _gl_field(sc, a, S.run_oracle(sc, "gl", cache))
+        st = P16.check(sc, b, a, cache, unexplained_fraction=3e-3)
+        beyond += st["pixels_gt2"] > 0
+        unexplained += st.get("unexplained_pixels", 0) > 0
+    assert unexplained <= 25, (beyond, unexplained)
+
+
+def test_own_pixel_background_fetch_is_what_llvmpipe_agrees_with():
+    """Evidence for oracle/ref_cpu.c: sample_own_pixel (a change made in round 1 after the oracle disagreed with the
+    HIP mixer). Three-way comparison on 16-bit scenes: llvmpipe running the reference shader against the oracle with
+    (a) the own-pixel background fetch and (b) the scanline-order bilinear fetch it had before. On the fixed goldens
+    the two are equally far from llvmpipe; on 200 random scenes (a) differs from llvmpipe in 58 105 samples against
+    65 243 for (b), and by more than 2 LSB16 in 11 368 against 15 156. Neither is 'right' where they differ (the read is
+    undefined there, see parity16.amplifying_pixels), but the own pixel is the defined part and the closer one."""
+    if not _gl():
+        pytest.skip("llvmpipe harness not available here")
+    from oracle import oracle as O
+    L = O.lib()
+    n = {"own0": 0, "bil0": 0, "own2": 0, "bil2": 0}
+    for sc in S.sixteen_bit_scenes() + [fuzz_scene(seed, 16) for seed in range(0, N_CPU, 2)]:
+        cache = {}
+        own = S.run_oracle(sc, "cpu", cache)
+        gl = _gl_field(sc, own, S.run_oracle(sc, "gl", cache)).astype(np.int32)
+        L.cpuref_set_background_bilinear(1)
+        try:
+            bil = S.run_oracle(sc, "cpu", cache).astype(np.int32)
+        finally:
+            L.cpuref_set_background_bilinear(0)
+        do, db = np.abs(own.astype(np.int32) - gl), np.abs(bil - gl)
+        n["own0"] += int((do > 0).sum()); n["bil0"] += int((db > 0).sum())
+        n["own2"] += int((do > 2).sum()); n["bil2"] += int((db > 2).sum())
+    assert n["own0"] <= n["bil0"] and n["own2"] <= n["bil2"], n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["8bit", "16bit"])
 def test_hip_matches_oracle_on_random_scenes(mode):
     import server_amd as A
     bits = 8 if mode == "8bit" else 16
     m = A.Mixer(channel_id=3, gpu=0)
-    worst = {"max": 0, "gt0": 0.0, "gt2": 0.0}
+    worst = {"max": 0, "gt0": 0.0, "gt2": 0.0, "max_outside_amplifying": 0, "scenes_beyond_2": 0}
     try:
         for seed in range(N_GPU):
             sc = fuzz_scene(seed, bits)
@@ -64,11 +123,18 @@ def test_hip_matches_oracle_on_random_scenes(mode):
                 # samples, and on EVERY odd code at opacity 0.5, where that noise decides the tie (seed 667: 3.7 %).
                 # Blends that divide by a small alpha, contrast and the chroma key's thresholds amplify single samples
                 # from there. The oracle's own distance to llvmpipe on 16-bit scenes is of the same kind and size.
-                assert st["gt2"] <= 3e-2, (seed, st)
-            worst = {k: max(worst[k], st[k]) for k in worst}
+                # So: a MAXIMUM of +-2 LSB16 at every pixel that is not an amplifying pixel of the scene
+                # (tests/parity16.py), and a bound on how many there are.
+                st = P16.check(sc, got, ref, cache)
+                assert st["gt2"] <= 2e-2, (seed, st)  # measured worst: 1.9e-2 (tests/golden/parity16_report.json)
+                worst["scenes_beyond_2"] += st["pixels_gt2"] > 0
+                worst["max_outside_amplifying"] = max(worst["max_outside_amplifying"], st["max_outside_amplifying"])
+            worst = {k: (max(worst[k], st[k]) if k in ("max", "gt0", "gt2") else worst[k]) for k in worst}
     finally:
         m.close()
     print("worst over %d scenes (%s): %s" % (N_GPU, mode, worst))
+    if mode == "16bit":
+        P16.REPORT["fuzz_800_scenes_16bit"] = worst
 
 
 @pytest.mark.gpu
@@ -102,7 +168,13 @@ def test_fast_kernel_on_random_unit_scale_stacks(bits, full):
                 else:
                     assert st["max"] == 0, (seed, st)
             else:
-                assert st["gt2"] <= 3e-2, (seed, st)
+                st = P16.check(sc, fast, ref, cache)  # +-2 LSB16 outside the scene's amplifying pixels
+                assert st["gt2"] <= 3e-3, (seed, st)  # measured worst: 3.5e-4 / 1.6e-3 with temporaries
+                key = "fuzz_fast_300_scenes_16bit" + ("_with_temporaries" if full else "")
+                w = P16.REPORT.setdefault(key, {"max": 0, "gt2": 0.0, "max_outside_amplifying": 0, "scenes_beyond_2": 0})
+                w["max"], w["gt2"] = max(w["max"], st["max"]), max(w["gt2"], st["gt2"])
+                w["max_outside_amplifying"] = max(w["max_outside_amplifying"], st["max_outside_amplifying"])
+                w["scenes_beyond_2"] += st["pixels_gt2"] > 0
             ran_fast += 1
     finally:
         m.close()
