@@ -161,6 +161,27 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
                              int nsurfaces, const cghip_draw* draws, int ndraws, unsigned flags,
                              cghip_ticket** out);
 
+/* ---- the entry point that allocates nothing. It has NO counterpart in the reference (whose renderer creates
+ *      textures and buffers per frame, image_mixer.cpp:95,128,177,187). It is for callers that cannot allocate: code
+ *      under HIP graph capture set-up, tight serving loops, harnesses that forbid hipMalloc. Same frame, same kernels
+ *      and the same result as cghip_mixer_render_async, but
+ *        - the frame is written to `device_out` (W*H*4*(bits/8) bytes of device memory on the mixer's GPU, the
+ *          caller's), and the call returns when it is complete (it blocks; no ticket, no readback);
+ *        - what the kernels need beyond sources and output - the op list and the surfaces a frame that is cut into
+ *          several launches hands from one launch to the next - lives in a per-GPU static device array of
+ *          CGHIP_NOALLOC_SCRATCH_BYTES, held until the process ends. A frame whose op list is longer than
+ *          CGHIP_NOALLOC_MAX_OPS or whose hand-over surfaces need more than the rest of the array is refused with
+ *          CGHIP_ERR_UNSUPPORTED (a 2160p 16-bit stack that is ONE launch, like BASELINE config 3, needs none);
+ *        - no hipMalloc / hipFree / hipHostMalloc / event or stream creation happens inside the call.
+ *      Every call on a GPU shares that GPU's array, which keeps the last call's contents; nothing in it has to start
+ *      at zero (a launch only loads surfaces an earlier launch of the same frame stored). Calls on one GPU are
+ *      serialised by the library; render_async frames do not use the array. ------------------------------------- */
+#define CGHIP_NOALLOC_MAX_OPS 256
+#define CGHIP_NOALLOC_SCRATCH_BYTES (48u << 20)
+int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, const cghip_surface* surfaces,
+                               int nsurfaces, const cghip_draw* draws, int ndraws, void* device_out,
+                               size_t device_out_bytes);
+
 /* ---- tickets: replaces future<array<const uint8_t>>::get (common/future.h:9-27) --------------- */
 int cghip_ticket_wait(cghip_ticket* ticket, const uint8_t** data, size_t* size); /* needs CGHIP_RENDER_READBACK */
 int cghip_ticket_device_ptr(cghip_ticket* ticket, const void** device_ptr, size_t* size);

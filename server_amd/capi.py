@@ -127,6 +127,8 @@ def lib():
         L.cghip_mixer_destroy.argtypes = [C.c_void_p]
         L.cghip_mixer_render_async.argtypes = [C.c_void_p, C.POINTER(Format), C.POINTER(Surface), C.c_int,
                                                C.POINTER(Draw), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+        L.cghip_mixer_render_noalloc.argtypes = [C.c_void_p, C.POINTER(Format), C.POINTER(Surface), C.c_int,
+                                                 C.POINTER(Draw), C.c_int, C.c_void_p, C.c_size_t]
         L.cghip_ticket_wait.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.cghip_ticket_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.cghip_ticket_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -162,6 +164,7 @@ def host():
         Hh.cghost_frame_destroy.argtypes = [C.c_void_p]
         Hh.cghost_mixer_visit_frame.argtypes = [C.c_void_p, C.c_void_p]
         Hh.cghost_mixer_render_async.argtypes = [C.c_void_p, C.POINTER(Format), C.c_int, C.POINTER(C.c_void_p)]
+        Hh.cghost_mixer_render_noalloc.argtypes = [C.c_void_p, C.POINTER(Format), C.c_void_p, C.c_size_t]
         Hh.cghost_future_get.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float)]
         Hh.cghost_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         Hh.cghost_device_gc.argtypes = [C.c_int]
@@ -330,6 +333,13 @@ class Mixer:
         self.last_kernel_ms = ms.value
         self._keep = []
         return out
+
+    def render_noalloc(self, device_ptr, nbytes, width, height, square_width=None, square_height=None, bits=8,
+                       field_mode=0):
+        """The pending scene into device memory of the caller through cghip_mixer_render_noalloc (blocking)."""
+        fmt = self._format(width, height, square_width, square_height, bits, field_mode)
+        check_host(self.H.cghost_mixer_render_noalloc(self.h, C.byref(fmt), C.c_void_p(device_ptr), C.c_size_t(nbytes)))
+        self._keep = []
 
     def flatten(self, width, height, square_width=None, square_height=None, bits=8, field_mode=0):
         fmt = self._format(width, height, square_width, square_height, bits, field_mode)

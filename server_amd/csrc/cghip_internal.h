@@ -124,4 +124,7 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
                                              int field_mode, int full, int fast, const KSpill* sp, int gw, int gh,
                                              hipStream_t stream);
 
+/* device address of this GPU's static scratch array (cghip_kernels.hip); looked up once per device, no allocation */
+extern "C" hipError_t cghip_scratch_address(int gpu, void** ptr, size_t* bytes);
+
 #endif

@@ -23,8 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/cghip.h" /* CGHIP_NOALLOC_SCRATCH_BYTES */
 #include "cghip_kops.h"
 
+#include <mutex>
 #include <type_traits>
 
 #define DEV __device__ __forceinline__
@@ -1682,6 +1684,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
 {
     composite_fast_body<BITS, true>(ops, nops, out, W, H, field_mode, sp);
+}
+
+/* ------------------------------------------------------------------ scratch of the allocation-free entry point */
+
+/* cghip_mixer_render_noalloc (include/cghip.h) may not allocate, so the device memory a frame needs BEYOND its source
+ * planes and its output - the op list the kernels walk, and the surfaces handed from one launch of a cut frame to the
+ * next (KSpill) - lives in this file-scope array: CGHIP_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.
+ * In host code the array's name is a host-side stand-in, not a device address: its device address is looked up once
+ * per device with hipGetSymbolAddress (with that device current; every GPU holds its own copy at its own address),
+ * and from then on only that pointer is used - as kernel argument and as copy destination. */
+static __device__ __align__(256) unsigned char scratch[CGHIP_NOALLOC_SCRATCH_BYTES];
+
+constexpr int   SCRATCH_MAX_GPUS = 64;
+static void*    g_scratch_ptr[SCRATCH_MAX_GPUS];
+static std::mutex g_scratch_mu;
+
+/* The device address of this GPU's scratch array; the first call on a GPU looks it up. No allocation. */
+extern "C" hipError_t cghip_scratch_address(int gpu, void** ptr, size_t* bytes)
+{
+    if (gpu < 0 || gpu >= SCRATCH_MAX_GPUS || !ptr)
+        return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[gpu]) {
+        hipError_t e = hipSetDevice(gpu);
+        if (e != hipSuccess)
+            return e;
+        void* p = nullptr;
+        e       = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess)
+            return e;
+        if (!p)
+            return hipErrorInvalidSymbol;
+        g_scratch_ptr[gpu] = p;
+    }
+    *ptr = g_scratch_ptr[gpu];
+    if (bytes)
+        *bytes = sizeof scratch;
+    return hipSuccess;
 }
 
 /* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */

@@ -140,6 +140,14 @@ int cghip_device_create(int gpu_index, cghip_device** out)
         delete d;
         return fail_hip(e, "hipStreamCreateWithFlags");
     }
+    /* set-up of the allocation-free entry point: this GPU's scratch array address, looked up once (no allocation) */
+    void* scratch = nullptr;
+    e             = cghip_scratch_address(gpu_index, &scratch, nullptr);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(d->upload_stream);
+        delete d;
+        return fail_hip(e, "hipGetSymbolAddress(scratch)");
+    }
     *out = d;
     return CGHIP_OK;
 }
@@ -583,6 +591,92 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     dev->frames_rendered++;
     dev->kernel_launches += t->launches;
     *out = t;
+    return CGHIP_OK;
+}
+
+/* The allocation-free variant (include/cghip.h). Op list and hand-over surfaces live in the GPU's static scratch
+ * array: [ CGHIP_NOALLOC_MAX_OPS KOps | RGBA1 | RGBA2 | KEY0 | KEY1 ], each surface region 256-byte aligned and only
+ * present when the plan needs it. */
+static std::mutex g_noalloc_mu[64];
+
+int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, const cghip_surface* surfaces,
+                               int nsurfaces, const cghip_draw* draws, int ndraws, void* device_out,
+                               size_t device_out_bytes)
+{
+    if (!mixer || !device_out)
+        return fail(CGHIP_ERR_INVALID, "bad arguments");
+    frame_plan plan; /* host memory only */
+    int        rc = plan_frame(format, surfaces, nsurfaces, draws, ndraws, &plan);
+    if (rc != CGHIP_OK)
+        return rc;
+    cghip_device* dev = mixer->dev;
+    for (cghip_plane* p : plan.planes)
+        if (p->stub || p->dev != dev)
+            return fail(CGHIP_ERR_INVALID, "plane lives on another device: route it with cghip_plane_peer_copy_async");
+    const size_t out_bytes = (size_t)format->width * format->height * 4 * (format->bits / 8);
+    if (device_out_bytes < out_bytes)
+        return fail(CGHIP_ERR_INVALID, "device_out is smaller than width * height * 4 * (bits / 8)");
+    if (((uintptr_t)device_out & 15) != 0)
+        return fail(CGHIP_ERR_INVALID, "device_out must be 16-byte aligned");
+    if (plan.ops.size() > CGHIP_NOALLOC_MAX_OPS)
+        return fail(CGHIP_ERR_UNSUPPORTED, "frame has more than CGHIP_NOALLOC_MAX_OPS (256) ops: use cghip_mixer_render_async");
+    if (dev->gpu < 0 || dev->gpu >= 64)
+        return fail(CGHIP_ERR_UNSUPPORTED, "gpu index beyond the scratch table");
+
+    CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
+    void*  base = nullptr;
+    size_t cap  = 0;
+    CGHIP_TRY_HIP(cghip_scratch_address(dev->gpu, &base, &cap));
+    /* lay the hand-over surfaces out behind the op list; refuse what does not fit */
+    const size_t ops_region = round_up((size_t)CGHIP_NOALLOC_MAX_OPS * sizeof(KOp), 256);
+    size_t       off        = ops_region;
+    void*        spill[4]   = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i)
+        if (plan.spill_mask & (1u << (KS_RGBA1 + i))) {
+            const size_t need = round_up((size_t)format->width * format->height * (i < 2 ? 4 : 1) * (format->bits / 8), 256);
+            if (off + need > cap) {
+                char msg[200];
+                snprintf(msg, sizeof msg,
+                         "frame is cut into %zu launches whose hand-over surfaces need more than the %zu scratch bytes "
+                         "of cghip_mixer_render_noalloc: use cghip_mixer_render_async",
+                         plan.segments.size(), cap - ops_region);
+                return fail(CGHIP_ERR_UNSUPPORTED, msg);
+            }
+            spill[i] = (char*)base + off;
+            off += need;
+        }
+
+    std::lock_guard<std::mutex> lock(g_noalloc_mu[dev->gpu]); /* one frame at a time in a GPU's scratch array */
+    hipStream_t                 st = mixer->stream;
+    for (cghip_plane* p : plan.planes) { /* uploads still in flight */
+        cghip_plane* root = p->parent ? p->parent : p;
+        if (!root->ready_seen.load(std::memory_order_acquire))
+            CGHIP_TRY_HIP(hipStreamWaitEvent(st, root->ready, 0));
+    }
+    if (!plan.ops.empty()) /* pageable source: the runtime stages it itself; ordered on the compositor's stream */
+        CGHIP_TRY_HIP(hipMemcpyAsync(base, plan.ops.data(), plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, st));
+    int        launches = 0;
+    hipError_t e        = hipSuccess;
+    for (const segment& sg : plan.segments) {
+        KSpill sp;
+        sp.rgba1 = spill[0], sp.rgba2 = spill[1], sp.key0 = spill[2], sp.key1 = spill[3];
+        sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
+        sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
+        e = cghip_launch_composite((const KOp*)base + sg.first, sg.count, device_out, format->width, format->height,
+                                   format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 : 0, &sp,
+                                   sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, st);
+        if (e != hipSuccess)
+            break;
+        ++launches;
+    }
+    /* the op list (host vector) and the scratch array must stay untouched until the launches are done */
+    const hipError_t es = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+        return fail_hip(e, "cghip_launch_composite");
+    if (es != hipSuccess)
+        return fail_hip(es, "hipStreamSynchronize");
+    dev->frames_rendered++;
+    dev->kernel_launches += launches;
     return CGHIP_OK;
 }
 

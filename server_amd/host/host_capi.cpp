@@ -312,6 +312,12 @@ int cghost_mixer_render(void* h, const cghip_format* f, void* out, size_t capaci
     });
 }
 
+/* the pending scene composited into the caller's device memory by the entry point that allocates nothing */
+int cghost_mixer_render_noalloc(void* h, const cghip_format* f, void* device_ptr, size_t bytes)
+{
+    return guarded([&] { static_cast<host_mixer*>(h)->mixer->render_into(to_desc(f), device_ptr, bytes); });
+}
+
 /* operator() without the get(): the deferred future is returned as a handle (core/mixer/mixer.cpp:70-91 keeps it
  * in a queue and calls get() one tick later). */
 struct pending_frame

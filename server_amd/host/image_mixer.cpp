@@ -539,6 +539,31 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
         });
     }
 
+    void render_into(const core::video_format_desc& format_desc, void* device_ptr, std::size_t bytes)
+    {
+        auto layers = std::move(layers_);
+        layers_.clear();
+        layer_path_.clear();
+        if (!mixer_)
+            throw not_supported("this image_mixer was created without a device (dry run): it cannot render");
+        std::vector<draw_call>     calls;
+        std::vector<cghip_surface> surfaces;
+        {
+            draw_recorder rec(format_desc, calls, surfaces);
+            rec.draw(0, layers);
+        }
+        std::vector<cghip_draw> draws;
+        draws.reserve(calls.size());
+        for (auto& c : calls)
+            draws.push_back(c.draw);
+        cghip_format fmt{format_desc.width, format_desc.height, format_desc.square_width, format_desc.square_height,
+                         format_desc.bits,  format_desc.field_mode};
+        /* an empty scene is the zero frame here too: one launch with no ops stores it */
+        check(cghip_mixer_render_noalloc(mixer_, &fmt, surfaces.data(), static_cast<int>(surfaces.size()), draws.data(),
+                                         static_cast<int>(draws.size()), device_ptr, bytes),
+              "cghip_mixer_render_noalloc");
+    }
+
     core::mutable_frame create_frame(const void* tag, const core::pixel_format_desc& desc) /* :306-331 */
     {
         if (!dev_)
@@ -582,6 +607,10 @@ core::mutable_frame image_mixer::create_frame(const void* tag, const core::pixel
 std::vector<draw_call> image_mixer::flatten(const core::video_format_desc& format_desc, std::vector<cghip_surface>* surfaces)
 {
     return impl_->flatten(format_desc, surfaces);
+}
+void image_mixer::render_into(const core::video_format_desc& format_desc, void* device_ptr, std::size_t bytes)
+{
+    impl_->render_into(format_desc, device_ptr, bytes);
 }
 float image_mixer::last_kernel_ms() const { return impl_->last_ms_; }
 void  image_mixer::set_readback(bool on) { impl_->readback_ = on; }

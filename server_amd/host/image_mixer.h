@@ -189,6 +189,10 @@ class image_mixer final
     /* Introspection (not in the reference interface): flatten the pending scene into the draw list the
      * renderer would issue, without rendering; and device-side timing of the last rendered frame. */
     std::vector<draw_call> flatten(const core::video_format_desc& format_desc, std::vector<cghip_surface>* surfaces);
+    /* Not in the reference interface: composites the pending scene straight into device memory of the caller
+       (format_desc.size bytes on this mixer's GPU) through the entry point that allocates nothing
+       (cghip_mixer_render_noalloc, include/cghip.h); returns when the frame is complete. */
+    void                   render_into(const core::video_format_desc& format_desc, void* device_ptr, std::size_t bytes);
     float                  last_kernel_ms() const;
     void                   set_readback(bool on); /* false: frames stay in HBM (kernel-only benchmarking) */
     /* interlaced channels (format_desc.field_mode 1 / 2): read back only the rows of the rendered field; the
