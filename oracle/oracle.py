@@ -134,6 +134,7 @@ def lib():
         L.cpuref_set_background_bilinear.argtypes = [C.c_int]
         L.cpuref_set_fetch_delta.argtypes = [C.c_float] * 4
         L.cpuref_set_snap_fetch.argtypes = [C.c_int]
+        L.cpuref_set_store_flip.argtypes = [C.c_uint]
         _lib = L
     return _lib
 

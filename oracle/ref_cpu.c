@@ -693,6 +693,27 @@ static void interpolate(const tri_setup* ts, int x, int y, float out[6])
         out[k] = (float)(ts->attr[0][k] + l1 * (ts->attr[1][k] - ts->attr[0][k]) + l2 * (ts->attr[2][k] - ts->attr[0][k]));
 }
 
+/* Test switch (tests/parity16.py): every store into a 16-bit render target lands on the code above or below the
+ * rounded one with probability 1/4 each (seeded hash of draw, pixel and channel; seeds 0xFFFFFFFF / 0xFFFFFFFE: every
+ * store one code up / down). It stands for an implementation
+ * whose arithmetic differs from the exact sequence by a few 1e-7 and therefore rounds to the neighbouring code now and
+ * then: a pixel whose final value moves by more than 2 LSB16 under it is one where the scene amplifies one LSB16 of an
+ * intermediate render target (a blend mode dividing by alpha, shader.frag:427-428). Never on in a parity comparison. */
+static unsigned g_store_flip = 0; /* 0 = off, else the seed */
+static unsigned g_draw_index = 0;
+void            cpuref_set_store_flip(unsigned seed) { g_store_flip = seed, g_draw_index = 0; }
+static int      store_flip(int x, int y, int k)
+{
+    if (g_store_flip >= 0xFFFFFFFEu) /* every store one code up (..FF) / down (..FE) */
+        return g_store_flip == 0xFFFFFFFFu ? 1 : -1;
+    uint64_t z = ((uint64_t)g_store_flip << 48) ^ ((uint64_t)g_draw_index << 34) ^ ((uint64_t)y << 18) ^ ((uint64_t)x << 2) ^ (uint64_t)k;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const unsigned r = (unsigned)(z >> 40) & 3u;
+    return r == 0 ? -1 : (r == 1 ? 1 : 0);
+}
+
 static void store(cpu_tex* bg, int x, int y, v4 rgba)
 {
     const size_t idx = ((size_t)y * bg->w + x) * bg->stride;
@@ -708,6 +729,10 @@ static void store(cpu_tex* bg, int x, int y, v4 rgba)
     }
     for (int k = 0; k < n; ++k) {
         unsigned v = to_unorm(ch[k], bg->bits);
+        if (g_store_flip && bg->bits == 16) {
+            const int f = (int)v + store_flip(x, y, k);
+            v           = (unsigned)(f < 0 ? 0 : (f > 65535 ? 65535 : f));
+        }
         if (bg->bits == 16)
             ((uint16_t*)bg->data)[idx + k] = (uint16_t)v;
         else
@@ -717,6 +742,7 @@ static void store(cpu_tex* bg, int x, int y, v4 rgba)
 
 static void cpu_draw(const ref_draw* d)
 {
+    g_draw_index++;
     cpu_tex* bg = (cpu_tex*)d->background;
     const int W = bg->w, H = bg->h;
 

@@ -23,6 +23,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+/* This file is compiled TWICE (csrc/Makefile): with -DCGHIP_FRAME_BITS=8 -ffp-contract=off into the kernels of 8-bit
+ * frames (bit-exact against the reference pipeline), and with -DCGHIP_FRAME_BITS=16 -ffp-contract=fast into the
+ * kernels of 16-bit frames (relaxed numerics, see divf below). Each object carries its own launcher
+ * (cghip_launch_composite8 / 16); the 8-bit object also holds what exists once: the dispatcher, the debug switches
+ * and the scratch array of the allocation-free entry point. */
+#ifndef CGHIP_FRAME_BITS
+#error "compile with -DCGHIP_FRAME_BITS=8 or 16 (see csrc/Makefile)"
+#endif
+
 #include "../../include/cghip.h" /* CGHIP_NOALLOC_SCRATCH_BYTES */
 #include "cghip_kops.h"
 
@@ -30,6 +39,9 @@
 #include <type_traits>
 
 #define DEV __device__ __forceinline__
+
+/* relaxed numerics: the object for 16-bit frames (see divf below) */
+constexpr bool RXF = CGHIP_FRAME_BITS == 16;
 
 /* compile-time loop: the per-pixel register arrays must never be indexed dynamically (that would put them
  * in scratch memory) */
@@ -64,7 +76,6 @@ struct Q {
 template <int BITS>
 DEV float quantize(float x)
 {
-#pragma clang fp contract(off)
     x             = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); /* NaN -> 0 like the clamp before a UNORM store */
     const float r = x * Q<BITS>::scale + Q<BITS>::magic; /* two roundings, never an fma (pragma above) */
     /* t = r - magic = k / 2^n exactly, result = fl(t * dequant) = fl(k * fl(1/(2^n-1))). One explicit fma does
@@ -270,6 +281,34 @@ DEV float fdiv(float a, float b)
     return __builtin_fmaf(r, rb, q);
 }
 
+/* ---- numerics of the 16-bit frame kernels (RX = true) ----------------------------------------------------------
+ * 8-bit frames are bit-exact against the reference pipeline: every operation above and below follows the shader's
+ * own sequence of roundings. 16-bit frames are the north star's extension with a tolerance of +-2 LSB16, and one
+ * LSB16 is 2^-16: an fp32 rounding (2^-24) is 1/256 of it. There the kernels evaluate the same formulas with fewer
+ * roundings instead of the same ones: multiply-adds are fused, x / c is x * (1 / c), a / b is a * rcp(b) (1 ulp),
+ * the YCbCr matrix acts directly on the sample codes, and the UNORM store after every draw is three fmas (fused
+ * blend with the clamp as an output modifier, round with the magic constant, back to [0,1]). The result differs from
+ * the exact sequence by a few 1e-7, i.e. it rounds to the neighbouring code for a few per cent of the samples; the
+ * draw-by-draw UNORM rounding itself is kept. tests/parity16.py bounds the MAXIMUM at +-2 LSB16 outside
+ * the pixels where the scene itself amplifies such noise. Instruction count on the headline frame: 223 M -> see
+ * DESIGN.md section 4. */
+template <bool RX>
+DEV float divf(float a, float b)
+{
+    if constexpr (RX)
+        return a * __builtin_amdgcn_rcpf(b);
+    else
+        return fdiv(a, b);
+}
+template <bool RX>
+DEV float divc(float x, float c, float rc)
+{
+    if constexpr (RX)
+        return x * rc;
+    else
+        return div_const(x, c, rc);
+}
+
 /* shader.frag:441-467; internal order x=blue y=green z=red w=alpha */
 DEV f4 ycbcra_to_rgba(float Y, float Cb, float Cr, float A, bool hd)
 {
@@ -277,13 +316,13 @@ DEV f4 ycbcra_to_rgba(float Y, float Cb, float Cr, float A, bool hd)
     const float cb = Cb * 255.0f - 128.0f, cr = Cr * 255.0f - 128.0f;
     f4          c;
     if (hd) {
-        c.z = div_const((yy + 1.793f * cr), 255.0f, 1.0f / 255.0f);
-        c.y = div_const((yy - 0.534f * cr - 0.213f * cb), 255.0f, 1.0f / 255.0f);
-        c.x = div_const((yy + 2.115f * cb), 255.0f, 1.0f / 255.0f);
+        c.z = divc<RXF>((yy + 1.793f * cr), 255.0f, 1.0f / 255.0f);
+        c.y = divc<RXF>((yy - 0.534f * cr - 0.213f * cb), 255.0f, 1.0f / 255.0f);
+        c.x = divc<RXF>((yy + 2.115f * cb), 255.0f, 1.0f / 255.0f);
     } else {
-        c.z = div_const((yy + 1.596f * cr), 255.0f, 1.0f / 255.0f);
-        c.y = div_const((yy - 0.813f * cr - 0.391f * cb), 255.0f, 1.0f / 255.0f);
-        c.x = div_const((yy + 2.018f * cb), 255.0f, 1.0f / 255.0f);
+        c.z = divc<RXF>((yy + 1.596f * cr), 255.0f, 1.0f / 255.0f);
+        c.y = divc<RXF>((yy - 0.813f * cr - 0.391f * cb), 255.0f, 1.0f / 255.0f);
+        c.x = divc<RXF>((yy + 2.018f * cb), 255.0f, 1.0f / 255.0f);
     }
     c.w = A;
     return c;
@@ -291,6 +330,7 @@ DEV f4 ycbcra_to_rgba(float Y, float Cb, float Cr, float A, bool hd)
 
 /* shader.frag:304-321. step() yields exactly 0 or 1, and mix(a, b, 0|1) = a*(1-t) + b*t is then exactly a or b,
  * so the seven mixes are selects. */
+template <bool RX = false>
 DEV f3 rgb2hsv(f3 c)
 {
     const bool  gb = !(c.y < c.z); /* step(c.b, c.g) == 1 */
@@ -299,7 +339,7 @@ DEV f3 rgb2hsv(f3 c)
     const f4    q  = {rp ? c.x : p.x, p.y, rp ? p.z : p.w, rp ? p.x : c.x};
     const float d  = q.x - __builtin_fminf(q.w, q.y);
     const float e  = 1.0e-10f;
-    return f3{__builtin_fabsf(q.z + fdiv(q.w - q.y, 6.0f * d + e)), fdiv(d, q.x + e), q.x};
+    return f3{__builtin_fabsf(q.z + divf<RX>(q.w - q.y, 6.0f * d + e)), divf<RX>(d, q.x + e), q.x};
 }
 DEV f3 hsv2rgb(f3 c)
 {
@@ -311,10 +351,10 @@ DEV f3 hsv2rgb(f3 c)
 }
 
 /* shader.frag:323-383,436-439; colour in internal order */
-template <class P>
+template <bool RX = false, class P>
 DEV f4 chroma_key(f4 c, const P& op)
 {
-    const f3    hsv      = rgb2hsv(f3{c.z, c.y, c.x}); /* c.bgra -> real r,g,b */
+    const f3    hsv      = rgb2hsv<RX>(f3{c.z, c.y, c.x}); /* c.bgra -> real r,g,b */
     const float hueDiff  = (0.5f - __builtin_fabsf(__builtin_fabsf(hsv.x - op.ch_target_hue) - 0.5f)) * 2.0f;
     const float satDiff  = __builtin_fminf(0.0f, op.ch_min_saturation - hsv.y);
     const float briDiff  = __builtin_fminf(0.0f, op.ch_min_brightness - hsv.z);
@@ -325,13 +365,13 @@ DEV f4 chroma_key(f4 c, const P& op)
     f3          sp       = hsv;
     float       diff     = hsv.x - op.ch_target_hue;
     diff                 = diff < -0.5f ? diff + 1.0f : (diff > 0.5f ? diff - 1.0f : diff);
-    const float dist     = div_const(__builtin_fabsf(diff), op.ch_spill, op.ch_inv_spill);
+    const float dist     = divc<RX>(__builtin_fabsf(diff), op.ch_spill, op.ch_inv_spill);
     if (dist < 1.0f) {
         sp.x = diff < 0.0f ? op.ch_target_hue - op.ch_spill : op.ch_target_hue + op.ch_spill;
         sp.y *= __builtin_fminf(1.0f, dist + op.ch_spill_saturation);
     }
     const f3    rgb   = hsv2rgb(sp);
-    const float t     = clamp01(div_const(dd - 1.0f, op.ch_soft_range, op.ch_inv_soft)); /* smoothstep(1, softness, d) */
+    const float t     = clamp01(divc<RX>(dd - 1.0f, op.ch_soft_range, op.ch_inv_soft)); /* smoothstep(1, softness, d) */
     const float alpha = 1.0f - t * t * (3.0f - 2.0f * t);
     if (op.flags & KF_CHROMA_MASK)
         return f4{alpha, alpha, alpha, 1.0f};
@@ -339,28 +379,39 @@ DEV f4 chroma_key(f4 c, const P& op)
 }
 
 /* shader.frag:76-86 */
-template <class P>
+template <bool RX = false, class P>
 DEV float levels1(float c, const P& op)
 {
-    float r = __builtin_fminf(div_const(__builtin_fmaxf(c - op.lv_min_input, 0.0f), op.lv_range, op.lv_inv_range), 1.0f);
+    float r;
+    if constexpr (RX) /* clamp((c - min) / range, 0, 1) as one fma with the clamp as its output modifier */
+        r = clamp01(__builtin_fmaf(c, op.lv_inv_range, -op.lv_min_input * op.lv_inv_range));
+    else
+        r = __builtin_fminf(div_const(__builtin_fmaxf(c - op.lv_min_input, 0.0f), op.lv_range, op.lv_inv_range), 1.0f);
     /* pow(r, 1/gamma), r in [0,1]. gamma == 1 (levels used for their ranges only) is exactly r; the log/exp pair
        would be a few ulp off it, enough to move one 8-bit sample in ~10^5 (found by tests/test_fuzz.py). */
     if (op.lv_inv_gamma != 1.0f)
         r = __builtin_amdgcn_exp2f(op.lv_inv_gamma * __builtin_amdgcn_logf(r));
     if (op.lv_min_output == 0.0f && op.lv_max_output == 1.0f)
         return r; /* mix(0, 1, r) = 0*(1-r) + 1*r is exactly r */
+    if constexpr (RX)
+        return __builtin_fmaf(r, op.lv_max_output - op.lv_min_output, op.lv_min_output);
     return mixf(op.lv_min_output, op.lv_max_output, r);
 }
 
 /* shader.frag:48-70 */
-template <class P>
+template <bool RX = false, class P>
 DEV void csb(f4& color, const P& op)
 {
     const bool hd = op.flags & KF_IS_HD;
     const f3   L  = hd ? f3{0.0722f, 0.7152f, 0.2126f} : f3{0.114f, 0.587f, 0.299f};
     f3         c  = {color.x, color.y, color.z};
     if (color.w > 0.0f) {
-        c.x = fdiv(c.x, color.w), c.y = fdiv(c.y, color.w), c.z = fdiv(c.z, color.w);
+        if constexpr (RX) {
+            const float rw = __builtin_amdgcn_rcpf(color.w);
+            c.x *= rw, c.y *= rw, c.z *= rw;
+        } else {
+            c.x = fdiv(c.x, color.w), c.y = fdiv(c.y, color.w), c.z = fdiv(c.z, color.w);
+        }
     }
     const f3    b = {c.x * op.brt, c.y * op.brt, c.z * op.brt};
     const float i = b.x * L.x + b.y * L.y + b.z * L.z;
@@ -558,7 +609,7 @@ DEV f4 swizzle_format(int pf, f4 a)
         case 3: return f4{a.w, a.x, a.y, a.z};
         case 4: return f4{a.y, a.z, a.w, a.x};
         case 7: {
-            const float l = div_const(a.x - 0.065f, 0.859f, 1.0f / 0.859f);
+            const float l = divc<RXF>(a.x - 0.065f, 0.859f, 1.0f / 0.859f);
             return f4{l, l, l, 1.0f};
         }
         case 8: return f4{a.z, a.y, a.x, 1.0f};
@@ -621,14 +672,14 @@ DEV f4 source_color_unit(const KOp& op, int px, int py)
 DEV f4 shade_adjust(const KOp& op, f4 color)
 {
     if (op.flags & KF_CHROMA)
-        color = chroma_key(color, op);
+        color = chroma_key<RXF>(color, op);
     if (op.flags & KF_LEVELS) {
-        color.x = levels1(color.x, op);
-        color.y = levels1(color.y, op);
-        color.z = levels1(color.z, op);
+        color.x = levels1<RXF>(color.x, op);
+        color.y = levels1<RXF>(color.y, op);
+        color.z = levels1<RXF>(color.z, op);
     }
     if (op.flags & KF_CSB)
-        csb(color, op);
+        csb<RXF>(color, op);
     return color;
 }
 
@@ -645,7 +696,6 @@ struct BlendArgs { /* what shade_blend reads of an op, by value */
 template <int MODE, class P>
 DEV f4 shade_blend(const P& op, f4 color, float lkey, float ykey, f4 back)
 {
-#pragma clang fp contract(off)
     /* The optional steps are made unconditional with neutral operands instead of wave-uniform branches (which
        the compiler turns into compute-both-and-select): x*1 == x, fma(x, 1, 0) == x and fma(x, -1, 1) == 1 - x
        exactly, so the roundings are those of the shader's own sequence. */
@@ -663,8 +713,8 @@ DEV f4 shade_blend(const P& op, f4 color, float lkey, float ykey, f4 back)
         blend = op.blend_mode != 0;
     if (blend) { /* shader.frag:427-428 */
         const float ba = back.w + 0.0000001f, fa = fore.w + 0.0000001f;
-        const f3    B = {fdiv(back.x, ba), fdiv(back.y, ba), fdiv(back.z, ba)};
-        const f3    F = {fdiv(fore.x, fa), fdiv(fore.y, fa), fdiv(fore.z, fa)};
+        const f3    B = {divf<RXF>(back.x, ba), divf<RXF>(back.y, ba), divf<RXF>(back.z, ba)};
+        const f3    F = {divf<RXF>(fore.x, fa), divf<RXF>(fore.y, fa), divf<RXF>(fore.z, fa)};
         f3          bc;
         if constexpr (MODE == MODE_RUNTIME)
             bc = get_blend_color(op.blend_mode, B, F);
@@ -682,7 +732,6 @@ DEV f4 shade_blend(const P& op, f4 color, float lkey, float ykey, f4 back)
 template <int BITS>
 DEV void shade_blend_mode4(const BlendArgs op, const f4 col[4], f4 D[4], const float K0[4], const float K1[4])
 {
-#pragma clang fp contract(off)
     const bool  inv = op.flags & KF_INVERT;
     const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
     f4          fore[4];
@@ -698,8 +747,8 @@ DEV void shade_blend_mode4(const BlendArgs op, const f4 col[4], f4 D[4], const f
         fore[i] = f4{__builtin_fmaf(c.x, im, ia0), __builtin_fmaf(c.y, im, ia0), __builtin_fmaf(c.z, im, ia0),
                      __builtin_fmaf(c.w, im, ia0)};
         const float ba = D[i].w + 0.0000001f, fa = fore[i].w + 0.0000001f;
-        B[i] = f3{fdiv(D[i].x, ba), fdiv(D[i].y, ba), fdiv(D[i].z, ba)};
-        F[i] = f3{fdiv(fore[i].x, fa), fdiv(fore[i].y, fa), fdiv(fore[i].z, fa)};
+        B[i] = f3{divf<RXF>(D[i].x, ba), divf<RXF>(D[i].y, ba), divf<RXF>(D[i].z, ba)};
+        F[i] = f3{divf<RXF>(fore[i].x, fa), divf<RXF>(fore[i].y, fa), divf<RXF>(fore[i].z, fa)};
     });
     const v12f r = get_blend_color4(op.blend_mode,
                                     v12f{B[0].x, B[0].y, B[0].z, B[1].x, B[1].y, B[1].z, B[2].x, B[2].y, B[2].z, B[3].x, B[3].y, B[3].z},
@@ -1329,7 +1378,7 @@ DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
     for (int i = 0; i < 4; ++i) {
         yy[i]    = 1.164f * ((SB == 8 ? Y[i] * sc : Y[i]) * 255.0f - 16.0f);
         cr[i]    = Cr[i] * 255.0f - 128.0f;
-        col[i].z = div_const((yy[i] + krr * cr[i]), 255.0f, 1.0f / 255.0f);
+        col[i].z = divc<RXF>((yy[i] + krr * cr[i]), 255.0f, 1.0f / 255.0f);
         col[i].w = Al[i];
         col[i].x = col[i].y = 0.0f;
     }
@@ -1339,8 +1388,8 @@ DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float cb = Cb[i] * 255.0f - 128.0f;
-            col[i].y       = div_const((yy[i] - kgr * cr[i] - kgb * cb), 255.0f, 1.0f / 255.0f);
-            col[i].x       = div_const((yy[i] + kbb * cb), 255.0f, 1.0f / 255.0f);
+            col[i].y       = divc<RXF>((yy[i] - kgr * cr[i] - kgb * cb), 255.0f, 1.0f / 255.0f);
+            col[i].x       = divc<RXF>((yy[i] + kbb * cb), 255.0f, 1.0f / 255.0f);
         }
     }
 }
@@ -1400,7 +1449,6 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
 template <int BITS, int VARIANT>
 DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
 {
-#pragma clang fp contract(off)
     float opa = op.opacity;
     asm volatile("" : "+v"(opa)); /* VALU ops with an SGPR operand issue at ~2/3 rate (tests/ubench): one v_mov instead */
     if (VARIANT == 0) {
@@ -1450,7 +1498,6 @@ DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4
 template <int BITS, bool SIMPLE>
 DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
 {
-#pragma clang fp contract(off)
     float opa = op.opacity;
     asm volatile("" : "+v"(opa)); /* see blend_rgba4 */
     const bool  key1 = op.dst == KS_KEY1;
@@ -1566,18 +1613,18 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
         /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
         if (h.flags & KF_CHROMA) {
             const ChromaV cp(op);
-            static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key(col[decltype(I)::value], cp); });
+            static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key<RXF>(col[decltype(I)::value], cp); });
         }
         if (h.flags & KF_LEVELS) {
             const LevelsV lp(op);
             static_for<0, P>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                col[i].x = levels1(col[i].x, lp), col[i].y = levels1(col[i].y, lp), col[i].z = levels1(col[i].z, lp);
+                col[i].x = levels1<RXF>(col[i].x, lp), col[i].y = levels1<RXF>(col[i].y, lp), col[i].z = levels1<RXF>(col[i].z, lp);
             });
         }
         if (h.flags & KF_CSB) {
             const CsbV bp(op);
-            static_for<0, P>([&](auto I) { csb(col[decltype(I)::value], bp); });
+            static_for<0, P>([&](auto I) { csb<RXF>(col[decltype(I)::value], bp); });
         }
         if (h.flags & KF_EDGE) { /* a box edge inside a lane's 4 pixels: a zero source leaves the target as it is */
             const uint32_t span = (uint32_t)(h.x1 - h.x0); /* one unsigned compare per pixel: x0 <= x < x1 */
@@ -1686,6 +1733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     composite_fast_body<BITS, true>(ops, nops, out, W, H, field_mode, sp);
 }
 
+#if CGHIP_FRAME_BITS == 8
 /* ------------------------------------------------------------------ scratch of the allocation-free entry point */
 
 /* cghip_mixer_render_noalloc (include/cghip.h) may not allocate, so the device memory a frame needs BEYOND its source
@@ -1724,22 +1772,37 @@ extern "C" hipError_t cghip_scratch_address(int gpu, void** ptr, size_t* bytes)
     return hipSuccess;
 }
 
-/* ------------------------------------------------------------------ launcher (called from cghip_runtime.cpp) */
+#endif /* CGHIP_FRAME_BITS == 8 */
+
+/* ------------------------------------------------------------------ launchers (called from cghip_runtime.cpp) */
 
 constexpr unsigned XCD_MIN_TILES = 4096; /* 1080p is 2160 tiles of the 4-pixels-per-lane kernel, 2160p 8100 */
-static int g_plain_tiles   = 0;
-extern "C" void cghip_debug_plain_tiles(int on) { g_plain_tiles = on; } /* measurements: tiles in dispatch order */
-static int g_pad_lds       = 0;
-static unsigned g_fast_rows = 4;
-extern "C" void cghip_debug_fast_rows(int rows) { g_fast_rows = rows >= 1 && rows <= 4 ? (unsigned)rows : 4u; }
+/* measurement switches, shared by both objects */
+#if CGHIP_FRAME_BITS == 8
+int      cghip_g_plain_tiles = 0;
+int      cghip_g_pad_lds     = 0;
+unsigned cghip_g_fast_rows   = 4;
+extern "C" void cghip_debug_plain_tiles(int on) { cghip_g_plain_tiles = on; } /* tiles in dispatch order */
+extern "C" void cghip_debug_fast_rows(int rows) { cghip_g_fast_rows = rows >= 1 && rows <= 4 ? (unsigned)rows : 4u; }
 /* occupancy experiments: dynamic LDS nobody touches, to cap the workgroups resident on a CU (160 KB per CU) */
-extern "C" void cghip_debug_pad_lds(int bytes) { g_pad_lds = bytes; }
+extern "C" void cghip_debug_pad_lds(int bytes) { cghip_g_pad_lds = bytes; }
+#else
+extern int      cghip_g_plain_tiles;
+extern int      cghip_g_pad_lds;
+extern unsigned cghip_g_fast_rows;
+#endif
 
-/* One launch of a frame (cghip_plan.cpp: segment). sp->gx0, gy0 and gw, gh: the pixel box the grid covers. */
-extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
-                                             int field_mode, int full, int fast, const KSpill* sp, int gw, int gh,
-                                             hipStream_t stream)
+/* One launch of a frame of CGHIP_FRAME_BITS bits (cghip_plan.cpp: segment). sp->gx0, gy0 and gw, gh: the pixel box
+ * the grid covers. */
+#if CGHIP_FRAME_BITS == 8
+#define LAUNCH_NAME cghip_launch_composite8
+#else
+#define LAUNCH_NAME cghip_launch_composite16
+#endif
+extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W, int H, int field_mode, int full,
+                                  int fast, const KSpill* sp, int gw, int gh, hipStream_t stream)
 {
+    constexpr int FB = CGHIP_FRAME_BITS;
     if (gw <= 0 || gh <= 0 || sp->gx0 < 0 || sp->gy0 < 0 || sp->gx0 + gw > W || sp->gy0 + gh > H)
         return hipErrorInvalidValue;
     KSpill s = *sp;
@@ -1755,31 +1818,35 @@ extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d
     if (fast) {
         if (s.gx0 != 0 || s.gy0 != 0)
             return hipErrorInvalidValue; /* the 4-pixels-per-lane kernel always covers the frame */
-        const unsigned rows = g_fast_rows; /* rows (= waves) per workgroup */
+        const unsigned rows = cghip_g_fast_rows; /* rows (= waves) per workgroup */
         block = dim3(64 * rows);
         const unsigned nbx = (unsigned)((gw + 255) / 256), nby = (unsigned)((gh + rows - 1) / rows);
-        const dim3     grid = tiles(nbx, nby, nbx * nby >= XCD_MIN_TILES && !g_plain_tiles);
-        if (bits == 8 && !full)
-            hipLaunchKernelGGL((cghip_composite_fast<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
-        else if (bits == 8)
-            hipLaunchKernelGGL((cghip_composite_fast_full<8>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
-        else if (!full)
-            hipLaunchKernelGGL((cghip_composite_fast<16>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+        const dim3     grid = tiles(nbx, nby, nbx * nby >= XCD_MIN_TILES && !cghip_g_plain_tiles);
+        if (!full)
+            hipLaunchKernelGGL((cghip_composite_fast<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else
-            hipLaunchKernelGGL((cghip_composite_fast_full<16>), grid, block, (size_t)g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            hipLaunchKernelGGL((cghip_composite_fast_full<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         return hipGetLastError();
     }
     const dim3 grid = tiles((unsigned)((gw + 63) / 64), (unsigned)((gh + 3) / 4), false);
-    if (bits == 8) {
-        if (full)
-            hipLaunchKernelGGL((cghip_composite<8, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
-        else
-            hipLaunchKernelGGL((cghip_composite<8, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
-    } else {
-        if (full)
-            hipLaunchKernelGGL((cghip_composite<16, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
-        else
-            hipLaunchKernelGGL((cghip_composite<16, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
-    }
+    if (full)
+        hipLaunchKernelGGL((cghip_composite<FB, true>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
+    else
+        hipLaunchKernelGGL((cghip_composite<FB, false>), grid, block, 0, stream, d_ops, nops, d_out, W, H, field_mode, s);
     return hipGetLastError();
 }
+
+#if CGHIP_FRAME_BITS == 8
+extern "C" hipError_t cghip_launch_composite16(const KOp* d_ops, int nops, void* d_out, int W, int H, int field_mode,
+                                               int full, int fast, const KSpill* sp, int gw, int gh, hipStream_t stream);
+extern "C" hipError_t cghip_launch_composite(const KOp* d_ops, int nops, void* d_out, int W, int H, int bits,
+                                             int field_mode, int full, int fast, const KSpill* sp, int gw, int gh,
+                                             hipStream_t stream)
+{
+    if (bits == 8)
+        return cghip_launch_composite8(d_ops, nops, d_out, W, H, field_mode, full, fast, sp, gw, gh, stream);
+    if (bits == 16)
+        return cghip_launch_composite16(d_ops, nops, d_out, W, H, field_mode, full, fast, sp, gw, gh, stream);
+    return hipErrorInvalidValue;
+}
+#endif
