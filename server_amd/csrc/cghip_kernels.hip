@@ -1163,6 +1163,12 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 /* Adjustment parameters copied into VGPRs once per op, for the 4-pixels-per-lane kernel: a VALU instruction with an
  * SGPR operand issues at half rate on gfx950 (tests/ubench/valu_rate: v_mul_f32 v, s, v 1.8 ns vs 1.0 ns), and each
  * of these is used 4..16 times per lane and op. Same field names as KOp, so the shader functions take either. */
+/* a scalar the compiler may not look through: arithmetic that depends on it stays where it is written */
+DEV int opaque_s(int v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
 DEV float in_vgpr(float x)
 {
     asm volatile("" : "+v"(x));
@@ -1223,7 +1229,7 @@ struct HotOp {
     int32_t  dst, local_key, layer_key, pixel_format;
     int32_t  x0, y0, x1, y1, unit_dx, unit_dy;
     float    opacity;
-    int32_t  fast_class, csx, csy, bits0;
+    int32_t  fetch_body, blend_body;
     uint64_t ptr0, ptr1, ptr2, ptr3;
     int32_t  w0, w1, w2, w3, h1;
 };
@@ -1231,14 +1237,14 @@ struct HotOp {
 DEV HotOp load_hot(const KOp& op)
 {
     HotOp h = {op.kind, op.flags, op.dst, op.local_key, op.layer_key, op.pixel_format, op.x0, op.y0, op.x1, op.y1,
-               op.unit_dx, op.unit_dy, op.opacity, op.fast_class, op.csx, op.csy, op.planes[0].bits,
+               op.unit_dx, op.unit_dy, op.opacity, op.fetch_body, op.blend_body,
                (uint64_t)op.planes[0].ptr, (uint64_t)op.planes[1].ptr, (uint64_t)op.planes[2].ptr,
                (uint64_t)op.planes[3].ptr, op.planes[0].w, op.planes[1].w, op.planes[2].w, op.planes[3].w,
                op.planes[1].h};
     asm volatile(""
                  : "+s"(h.kind), "+s"(h.flags), "+s"(h.dst), "+s"(h.local_key), "+s"(h.layer_key), "+s"(h.pixel_format),
                    "+s"(h.x0), "+s"(h.y0), "+s"(h.x1), "+s"(h.y1), "+s"(h.unit_dx), "+s"(h.unit_dy), "+s"(h.opacity),
-                   "+s"(h.fast_class), "+s"(h.csx), "+s"(h.csy), "+s"(h.bits0), "+s"(h.ptr0), "+s"(h.ptr1),
+                   "+s"(h.fetch_body), "+s"(h.blend_body), "+s"(h.ptr0), "+s"(h.ptr1),
                    "+s"(h.ptr2), "+s"(h.ptr3), "+s"(h.w0), "+s"(h.w1), "+s"(h.w2), "+s"(h.w3), "+s"(h.h1));
     return h;
 }
@@ -1252,12 +1258,19 @@ struct Row3 {
 /* Row address = wave-uniform base (the row index is scalar: every lane of a wave is on the same output row) plus a
  * 32-bit per-lane byte offset, so the loads take the SGPR-base + VGPR-offset form instead of a 64-bit multiply-add
  * per lane and load. */
+/* wave-uniform address of row r of a plane with w texels of B bytes per row: planes are smaller than 4 GiB
+ * (cghip_runtime.cpp: plane_new), so the offset is ONE 32-bit scalar multiply, not a 64-bit product of sign-extended
+ * operands (ten scalar instructions per plane and op) */
+DEV GB row_base(uint64_t ptr, int r, int w, uint32_t B)
+{
+    return (GB)ptr + (size_t)((uint32_t)r * ((uint32_t)w * B));
+}
 template <int SB, int HALF>
 DEV Row3 load_row(uint64_t ptr, int w, int r, int sx)
 {
     Row3 o = {0, 0, 0};
     constexpr uint32_t B = SB / 8;
-    const GB row = (GB)ptr + (size_t)r * (size_t)w * B; /* scalar */
+    const GB row = row_base(ptr, r, w, B); /* scalar */
     if (!HALF) {
         if (SB == 16) {
             const u32x2 v = load_at<u32x2>(row, (uint32_t)sx * B);
@@ -1394,6 +1407,119 @@ DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
     }
 }
 
+/* ---- the same for 16-bit planes in 16-bit frames (relaxed numerics, see divf) ----
+ * Between the sample codes and the colour there is nothing but affine maps: code / 65535, the 1/4 - 3/4 lerps of the
+ * half-resolution chroma planes, Y' = 1.164 (255 Y - 16), the matrix, / 255 (shader.frag:441-467). Composed:
+ *     R = aY Yc + aR Crc + cR,  G = aY Yc + aGr Crc + aGb Cbc + cG,  B = aY Yc + aB Cbc + cB
+ * on the codes Yc and the lerped chroma codes Cbc, Crc, with coefficients rounded once from double: 7 fmas per pixel
+ * instead of 27 operations, a few 1e-8 from the exact value where the shader's own sequence is a few 1e-7 from it. */
+struct YCoef {
+    float aY, aR, cR, aGr, aGb, cG, aB, cB;
+};
+DEV YCoef ycoef16(const KOp& o) /* from the planner (cghip_plan.cpp: classify_fast), moved to VGPRs once per op */
+{
+    return YCoef{in_vgpr(o.ycoef[0]), in_vgpr(o.ycoef[1]), in_vgpr(o.ycoef[2]), in_vgpr(o.ycoef[3]),
+                 in_vgpr(o.ycoef[4]), in_vgpr(o.ycoef[5]), in_vgpr(o.ycoef[6]), in_vgpr(o.ycoef[7])};
+}
+/* four chroma CODES (not normalised) of one plane row for a lane's pixels */
+template <int HX>
+DEV void chroma_codes_row(const Row3 r, float o[4])
+{
+    if (!HX) {
+        o[0] = (float)(r.a & 0xffff), o[1] = (float)(r.a >> 16), o[2] = (float)(r.b & 0xffff), o[3] = (float)(r.b >> 16);
+    } else {
+        const float t0 = (float)(r.a & 0xffff), t1 = (float)(r.a >> 16), tl = (float)r.b, tr = (float)r.c;
+        const float d  = t1 - t0;
+        o[0] = __builtin_fmaf(0.75f, t0 - tl, tl), o[1] = __builtin_fmaf(0.25f, d, t0);
+        o[2] = __builtin_fmaf(0.75f, d, t0), o[3] = __builtin_fmaf(0.25f, tr - t1, t1);
+    }
+}
+template <int HX, int HY>
+DEV void chroma_codes(const Row3 t, const Row3 u, int sy, float o[4])
+{
+    chroma_codes_row<HX>(t, o);
+    if (HY) {
+        float b[4];
+        chroma_codes_row<HX>(u, b);
+        const float w = (sy & 1) ? 0.25f : 0.75f; /* see convert_chroma */
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = __builtin_fmaf(w, b[i] - o[i], o[i]);
+    }
+}
+/* byte offsets of a lane's chroma texels in a half-width row: the aligned pair, the left and the right neighbour
+ * (clamped to the edge); Cb and Cr planes have one geometry, so one set serves both */
+struct ChromaOff {
+    uint32_t a, l, r;
+};
+template <int HX>
+DEV Row3 load_chroma16(uint64_t ptr, int w, int row, int sx, const ChromaOff o)
+{
+    Row3     v = {0, 0, 0};
+    const GB b = row_base(ptr, row, w, 2u); /* scalar */
+    if (!HX) {
+        const u32x2 q = load_at<u32x2>(b, (uint32_t)sx * 2u);
+        v.a = q.x, v.b = q.y;
+    } else {
+        v.a = load_at<uint32_t>(b, o.a);
+        v.b = load_at<uint16_t>(b, o.l);
+        v.c = load_at<uint16_t>(b, o.r);
+    }
+    return v;
+}
+template <int HX, int HY>
+DEV void fetch_planar16r(const KOp& kop, const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
+{
+    const int  r0    = (sy - 1) >> 1;
+    const int  ra    = HY ? iclamp(r0, 0, op.h1 - 1) : sy;
+    const int  rb    = HY ? iclamp(r0 + 1, 0, op.h1 - 1) : sy;
+    const bool alpha = op.pixel_format == 6;
+    ChromaOff  co    = {0, 0, 0};
+    if (HX) {
+        const int k = sx >> 1;
+        co.a = (uint32_t)k * 2u, co.l = (uint32_t)imax(k - 1, 0) * 2u, co.r = (uint32_t)imin(k + 2, op.w1 - 1) * 2u;
+    }
+    /* all loads first */
+    const u32x2 yv  = load_at<u32x2>(row_base(op.ptr0, sy, op.w0, 2u), (uint32_t)sx * 2u);
+    const Row3  cr0 = load_chroma16<HX>(op.ptr2, op.w1, ra, sx, co);
+    Row3        cb0 = {0, 0, 0}, cb1 = {0, 0, 0}, cr1 = {0, 0, 0};
+    u32x2       av  = {0, 0};
+    if (HY)
+        cr1 = load_chroma16<HX>(op.ptr2, op.w1, rb, sx, co);
+    if (!red_only) {
+        cb0 = load_chroma16<HX>(op.ptr1, op.w1, ra, sx, co);
+        if (HY)
+            cb1 = load_chroma16<HX>(op.ptr1, op.w1, rb, sx, co);
+    }
+    if (alpha)
+        av = load_at<u32x2>(row_base(op.ptr3, sy, op.w0, 2u), (uint32_t)sx * 2u);
+
+    const YCoef k = ycoef16(kop);
+    const float Y[4] = {(float)(yv.x & 0xffff), (float)(yv.x >> 16), (float)(yv.y & 0xffff), (float)(yv.y >> 16)};
+    float       Cr[4], Cb[4] = {0, 0, 0, 0};
+    chroma_codes<HX, HY>(cr0, cr1, sy, Cr);
+    if (!red_only)
+        chroma_codes<HX, HY>(cb0, cb1, sy, Cb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        col[i].z = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cr[i], k.aR, k.cR));
+        col[i].w = 1.0f;
+        col[i].x = col[i].y = 0.0f;
+    }
+    if (alpha) { /* wave-uniform; the empty asm keeps it a branch (as selects every draw paid 12 instructions for it) */
+        asm volatile("");
+        col[0].w = (float)(av.x & 0xffff) * (1.0f / 65535.0f), col[1].w = (float)(av.x >> 16) * (1.0f / 65535.0f);
+        col[2].w = (float)(av.y & 0xffff) * (1.0f / 65535.0f), col[3].w = (float)(av.y >> 16) * (1.0f / 65535.0f);
+    }
+    if (!red_only) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            col[i].y = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cr[i], k.aGr, __builtin_fmaf(Cb[i], k.aGb, k.cG)));
+            col[i].x = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cb[i], k.aB, k.cB));
+        }
+    }
+}
+
 /* source colours of four pixels from one 4-channel plane (bgra / rgba / argb / abgr, shader.frag:487-498). The
  * format swizzle is a byte permute of the raw texel (selector picked by scalar selects), so the conversion that
  * follows is the same straight line for all four formats. Internal order x,y,z,w = memory samples
@@ -1409,7 +1535,7 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
             const uint32_t t = load_at<uint32_t>((GB)op.ptr0, 0u);
             v                = u32x4{t, t, t, t};
         } else {
-            v = load_at<u32x4>((GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 4, (uint32_t)sx * 4u);
+            v = load_at<u32x4>(row_base(op.ptr0, sy, op.w0, 4u), (uint32_t)sx * 4u);
         }
         const uint32_t m[4] = {v.x, v.y, v.z, v.w};
         const float    sc   = 1.0f / 255.0f;
@@ -1427,7 +1553,7 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
             const u32x2 t = load_at<u32x2>((GB)op.ptr0, 0u);
             v = w = u32x4{t.x, t.y, t.x, t.y};
         } else {
-            const GB row = (GB)op.ptr0 + (size_t)sy * (size_t)op.w0 * 8;
+            const GB row = row_base(op.ptr0, sy, op.w0, 8u);
             v = load_at<u32x4>(row, (uint32_t)sx * 8u), w = load_at<u32x4>(row, (uint32_t)sx * 8u + 16u);
         }
         const uint32_t m[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
@@ -1442,22 +1568,28 @@ DEV void fetch_packed(const HotOp& op, int sx, int sy, f4 col[4])
     }
 }
 
-/* shader.frag:532-541 for four pixels onto the RGBA target. SIMPLE: no keys, no invert, linear keyer: the
- * neutral-operand steps of shade_blend() dropped (x*1, fma(x,1,0) are exact, so the results are the same). */
+/* shader.frag:532-541 for four pixels in two steps. (1) fore4 / fore_key4: the fore colour after keys, opacity and
+ * invert, and the factor `ia` the background is multiplied with (1 - fore.a, or 1 for the additive keyer), in the
+ * variant the planner picked (KOp::blend_body); the variants drop the neutral-operand steps of shade_blend() (x * 1,
+ * fma(x, 1, 0) are exact, so the results are the same). (2) ONE place where the surface registers are rewritten,
+ * store_rgba4 / the key select: when every variant wrote the loop-carried surfaces itself, the variants' results met at
+ * the loop latch in different registers and every op paid 26 register copies there. */
+struct Fore {
+    f4    f[4];
+    float ia[4];
+};
 /* VARIANT 0: no keys, no invert, linear keyer. 1: exactly one key (local or layer), else like 0: the usual keyed
  * fill. 2: everything, optional steps made unconditional with neutral operands. */
-template <int BITS, int VARIANT>
-DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4], const float K1[4])
+template <int VARIANT>
+DEV void fore4(const HotOp& op, const f4 col[4], const float K0[4], const float K1[4], Fore& o)
 {
     float opa = op.opacity;
     asm volatile("" : "+v"(opa)); /* VALU ops with an SGPR operand issue at ~2/3 rate (tests/ubench): one v_mov instead */
     if (VARIANT == 0) {
         static_for<0, 4>([&](auto I) {
-            constexpr int i  = decltype(I)::value;
-            const f4      f  = {col[i].x * opa, col[i].y * opa, col[i].z * opa, col[i].w * opa};
-            const float   ia = 1.0f - f.w;
-            S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
-                      quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
+            constexpr int i = decltype(I)::value;
+            o.f[i]  = f4{col[i].x * opa, col[i].y * opa, col[i].z * opa, col[i].w * opa};
+            o.ia[i] = 1.0f - o.f[i].w;
         });
     } else if (VARIANT == 1) {
         const bool from1 = (op.local_key != KS_NONE ? op.local_key : op.layer_key) == KS_KEY1;
@@ -1466,10 +1598,8 @@ DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4
             const float   k = from1 ? K1[i] : K0[i];
             f4            c = col[i];
             c.x *= k, c.y *= k, c.z *= k, c.w *= k;
-            const f4    f  = {c.x * opa, c.y * opa, c.z * opa, c.w * opa};
-            const float ia = 1.0f - f.w;
-            S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
-                      quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
+            o.f[i]  = f4{c.x * opa, c.y * opa, c.z * opa, c.w * opa};
+            o.ia[i] = 1.0f - o.f[i].w;
         });
     } else {
         const bool  lk = op.local_key != KS_NONE, yk = op.layer_key != KS_NONE;
@@ -1484,45 +1614,59 @@ DEV void blend_rgba4(const HotOp& op, const f4 col[4], f4 S[4], const float K0[4
             c.x *= k1, c.y *= k1, c.z *= k1, c.w *= k1;
             c.x *= k2, c.y *= k2, c.z *= k2, c.w *= k2;
             c.x *= opa, c.y *= opa, c.z *= opa, c.w *= opa;
-            const f4    f  = {__builtin_fmaf(c.x, im, ia0), __builtin_fmaf(c.y, im, ia0), __builtin_fmaf(c.z, im, ia0),
-                              __builtin_fmaf(c.w, im, ia0)};
-            const float ia = add ? 1.0f : 1.0f - f.w;
-            S[i] = f4{quantize<BITS>(f.x + ia * S[i].x), quantize<BITS>(f.y + ia * S[i].y),
-                      quantize<BITS>(f.z + ia * S[i].z), quantize<BITS>(f.w + ia * S[i].w)};
+            o.f[i]  = f4{__builtin_fmaf(c.x, im, ia0), __builtin_fmaf(c.y, im, ia0), __builtin_fmaf(c.z, im, ia0),
+                         __builtin_fmaf(c.w, im, ia0)};
+            o.ia[i] = add ? 1.0f : 1.0f - o.f[i].w;
         });
     }
 }
-
-/* same onto a key surface: only the red slot is stored (image_mixer.cpp:174-183), so only red and alpha are
- * evaluated. Keys of a key draw, if any, come from KEY0 like in cghip_composite. */
-template <int BITS, bool SIMPLE>
-DEV void blend_key4(const HotOp& op, const f4 col[4], float K0[4], float K1[4])
+/* the same for a draw into a key surface: only the red slot is stored (image_mixer.cpp:174-183), so only red (f.z)
+ * and alpha (f.w) are evaluated. Keys of a key draw, if any, come from KEY0 like in cghip_composite. */
+template <bool SIMPLE>
+DEV void fore_key4(const HotOp& op, const f4 col[4], const float K0[4], Fore& o)
 {
     float opa = op.opacity;
-    asm volatile("" : "+v"(opa)); /* see blend_rgba4 */
-    const bool  key1 = op.dst == KS_KEY1;
+    asm volatile("" : "+v"(opa));
     const bool  lk = op.local_key != KS_NONE, yk = op.layer_key != KS_NONE;
     const bool  inv = op.flags & KF_INVERT, add = op.flags & KF_ADDITIVE;
     const float im = inv ? -1.0f : 1.0f, ia0 = inv ? 1.0f : 0.0f;
     static_for<0, 4>([&](auto I) {
-        constexpr int i  = decltype(I)::value;
-        const float   a0 = K0[i], a1 = K1[i];
-        const float   back = key1 ? a1 : a0;
+        constexpr int i = decltype(I)::value;
         float         z = col[i].z, w = col[i].w, ia;
         if (SIMPLE) {
             z *= opa, w *= opa;
             ia = 1.0f - w;
         } else {
-            const float k1 = lk ? a0 : 1.0f, k2 = yk ? a0 : 1.0f;
+            const float k1 = lk ? K0[i] : 1.0f, k2 = yk ? K0[i] : 1.0f;
             z *= k1, w *= k1;
             z *= k2, w *= k2;
             z *= opa, w *= opa;
             z  = __builtin_fmaf(z, im, ia0), w = __builtin_fmaf(w, im, ia0);
             ia = add ? 1.0f : 1.0f - w;
         }
-        const float q = quantize<BITS>(z + ia * back);
-        K0[i]         = key1 ? a0 : q;
-        K1[i]         = key1 ? q : a1;
+        o.f[i]  = f4{0.0f, 0.0f, z, w};
+        o.ia[i] = ia;
+    });
+}
+/* fore + ia * back, then the UNORM store (shader.frag:429-433,541) */
+template <int BITS>
+DEV void store_rgba4(const Fore& o, f4 S[4])
+{
+    static_for<0, 4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        S[i] = f4{quantize<BITS>(o.f[i].x + o.ia[i] * S[i].x), quantize<BITS>(o.f[i].y + o.ia[i] * S[i].y),
+                  quantize<BITS>(o.f[i].z + o.ia[i] * S[i].z), quantize<BITS>(o.f[i].w + o.ia[i] * S[i].w)};
+    });
+}
+template <int BITS>
+DEV void store_key4(const Fore& o, bool key1, float K0[4], float K1[4])
+{
+    static_for<0, 4>([&](auto I) {
+        constexpr int i  = decltype(I)::value;
+        const float   a0 = K0[i], a1 = K1[i];
+        const float   q  = quantize<BITS>(o.f[i].z + o.ia[i] * (key1 ? a1 : a0));
+        K0[i]            = key1 ? a0 : q;
+        K1[i]            = key1 ? q : a1;
     });
 }
 
@@ -1586,30 +1730,41 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
            multiples of 4 (a lane is all in or all out) unless the op carries KF_EDGE, see below. */
         if (clr | !((y >= h.y0) & (y < h.y1) & (px0 > h.x0 - P) & (px0 < h.x1)))
             continue;
-        const int  sx = px0 + h.unit_dx, sy = y + h.unit_dy;
-        const bool s16 = h.bits0 == 16;
-        const bool red_only = h.dst >= KS_KEY0 && !(h.flags & (KF_CHROMA | KF_LEVELS | KF_CSB));
+        /* Source colour: the body the planner picked (KOp::fetch_body). Each body starts from an OPAQUE copy of the
+           source row: left to itself the compiler hoists the row-address arithmetic of all ten bodies in front of the
+           switch, where every op and wave paid ~90 scalar instructions for bodies it does not run - and the scalar
+           unit is shared by the CU's four SIMDs. */
+        const int  sx = px0 + h.unit_dx;
+        const bool red_only = h.flags & KF_RED_ONLY;
         f4         col[P];
-        if (FULL && h.kind == KOP_DRAW_SURFACE) {
-            const bool from2 = op.src_surface == KS_RGBA2;
-            static_for<0, P>([&](auto I) { col[decltype(I)::value] = sel4(from2, S2[decltype(I)::value], S1[decltype(I)::value]); });
-        } else if (h.fast_class == FC_PACKED) {
-            if (s16)
-                fetch_packed<16>(h, sx, sy, col);
-            else
-                fetch_packed<8>(h, sx, sy, col);
-        } else {
-            switch ((s16 ? 4 : 0) + h.csx + 2 * h.csy) {
-                case 0: fetch_planar<8, 0, 0>(h, sx, sy, red_only, col); break;
-                case 1: fetch_planar<8, 1, 0>(h, sx, sy, red_only, col); break;
-                case 2: fetch_planar<8, 0, 1>(h, sx, sy, red_only, col); break;
-                case 3: fetch_planar<8, 1, 1>(h, sx, sy, red_only, col); break;
-                case 4: fetch_planar<16, 0, 0>(h, sx, sy, red_only, col); break;
-                case 5: fetch_planar<16, 1, 0>(h, sx, sy, red_only, col); break;
-                case 6: fetch_planar<16, 0, 1>(h, sx, sy, red_only, col); break;
-                default: fetch_planar<16, 1, 1>(h, sx, sy, red_only, col); break;
-            }
+#define SY opaque_s(y + h.unit_dy)
+#define PLANAR16(HX, HY)                                                                                               \
+    if constexpr (BITS == 16)                                                                                          \
+        fetch_planar16r<HX, HY>(op, h, sx, SY, red_only, col);                                                         \
+    else                                                                                                               \
+        fetch_planar<16, HX, HY>(h, sx, SY, red_only, col);
+        switch (h.fetch_body) {
+            case FB_SURFACE:
+                if constexpr (FULL) {
+                    const bool from2 = op.src_surface == KS_RGBA2;
+                    static_for<0, P>([&](auto I) { col[decltype(I)::value] = sel4(from2, S2[decltype(I)::value], S1[decltype(I)::value]); });
+                } else {
+                    static_for<0, P>([&](auto I) { col[decltype(I)::value] = f4{0, 0, 0, 0}; }); /* never planned */
+                }
+                break;
+            case FB_PACKED8: fetch_packed<8>(h, sx, SY, col); break;
+            case FB_PACKED16: fetch_packed<16>(h, sx, SY, col); break;
+            case FB_PLANAR8 + 0: fetch_planar<8, 0, 0>(h, sx, SY, red_only, col); break;
+            case FB_PLANAR8 + 1: fetch_planar<8, 1, 0>(h, sx, SY, red_only, col); break;
+            case FB_PLANAR8 + 2: fetch_planar<8, 0, 1>(h, sx, SY, red_only, col); break;
+            case FB_PLANAR8 + 3: fetch_planar<8, 1, 1>(h, sx, SY, red_only, col); break;
+            case FB_PLANAR16 + 0: PLANAR16(0, 0) break;
+            case FB_PLANAR16 + 1: PLANAR16(1, 0) break;
+            case FB_PLANAR16 + 2: PLANAR16(0, 1) break;
+            default: PLANAR16(1, 1) break;
         }
+#undef PLANAR16
+#undef SY
         /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
         if (h.flags & KF_CHROMA) {
             const ChromaV cp(op);
@@ -1633,26 +1788,43 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 col[i] = sel4((uint32_t)(px0 + i - h.x0) < span, col[i], f4{0, 0, 0, 0});
             });
         }
-        const bool simple = h.local_key == KS_NONE && h.layer_key == KS_NONE && !(h.flags & (KF_INVERT | KF_ADDITIVE));
-        if (h.dst >= KS_KEY0) {
-            if (simple)
-                blend_key4<BITS, true>(h, col, K0, K1);
+        if constexpr (!FULL) {
+            /* fore colour and background factor: the body the planner picked (KOp::blend_body) ... */
+            Fore fo;
+            switch (h.blend_body) {
+                case BB_RGBA_SIMPLE: fore4<0>(h, col, K0, K1, fo); break;
+                case BB_RGBA_ONE_KEY: fore4<1>(h, col, K0, K1, fo); break;
+                case BB_KEY_SIMPLE: fore_key4<true>(h, col, K0, fo); break;
+                case BB_KEY_GENERAL: fore_key4<false>(h, col, K0, fo); break;
+                default: fore4<2>(h, col, K0, K1, fo); break;
+            }
+            /* ... and ONE place per surface where its registers are rewritten */
+            if (h.dst >= KS_KEY0)
+                store_key4<BITS>(fo, h.dst == KS_KEY1, K0, K1);
             else
-                blend_key4<BITS, false>(h, col, K0, K1);
+                store_rgba4<BITS>(fo, S);
         } else {
-            const bool plain_keyer = !(h.flags & (KF_INVERT | KF_ADDITIVE));
-            const bool one_key     = (h.local_key != KS_NONE) != (h.layer_key != KS_NONE);
-            auto       blend_into  = [&](f4(&D)[P]) {
-                if (FULL && op.blend_mode != 0) { /* a layer temporary composited with its blend mode */
-                    shade_blend_mode4<BITS>(BlendArgs{h.flags, h.local_key, h.layer_key, h.opacity, op.blend_mode}, col, D, K0, K1);
-                } else if (simple)
-                    blend_rgba4<BITS, 0>(h, col, D, K0, K1);
-                else if (plain_keyer && one_key)
-                    blend_rgba4<BITS, 1>(h, col, D, K0, K1);
-                else
-                    blend_rgba4<BITS, 2>(h, col, D, K0, K1);
+            /* With the two temporaries the kernel sits at its 128-register bound: carrying the fore colour of four
+               pixels across a merge spilled (config 4: 0.025 -> 0.042 ms), so here every variant rewrites its surface
+               itself. */
+            auto blend_into = [&](f4(&D)[P]) {
+                Fore fo;
+                switch (h.blend_body) {
+                    case BB_RGBA_SIMPLE: fore4<0>(h, col, K0, K1, fo), store_rgba4<BITS>(fo, D); break;
+                    case BB_RGBA_ONE_KEY: fore4<1>(h, col, K0, K1, fo), store_rgba4<BITS>(fo, D); break;
+                    case BB_MODE: /* a layer temporary composited with its blend mode */
+                        shade_blend_mode4<BITS>(BlendArgs{h.flags, h.local_key, h.layer_key, h.opacity, op.blend_mode}, col, D, K0, K1);
+                        break;
+                    default: fore4<2>(h, col, K0, K1, fo), store_rgba4<BITS>(fo, D); break;
+                }
             };
-            if (!FULL || h.dst == KS_RGBA0)
+            if (h.blend_body == BB_KEY_SIMPLE) {
+                Fore fo;
+                fore_key4<true>(h, col, K0, fo), store_key4<BITS>(fo, h.dst == KS_KEY1, K0, K1);
+            } else if (h.blend_body == BB_KEY_GENERAL) {
+                Fore fo;
+                fore_key4<false>(h, col, K0, fo), store_key4<BITS>(fo, h.dst == KS_KEY1, K0, K1);
+            } else if (h.dst == KS_RGBA0)
                 blend_into(S);
             else if (h.dst == KS_RGBA1)
                 blend_into(S1);

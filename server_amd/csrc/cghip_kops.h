@@ -31,7 +31,9 @@ enum KOpFlags : uint32_t {
     KF_UNIT_SCALE  = 1u << 8, /* KF_RECT and plane 0 maps 1:1 onto output pixels at an integer offset */
     KF_ADDITIVE    = 1u << 9, /* keyer::additive */
     KF_EDGE        = 1u << 11, /* fast kernel: x0 or x1 is not a multiple of 4, lanes on the box edge mask their pixels */
-    KF_SOLID       = 1u << 10 /* KF_RECT and the source is one 1x1 packed texel (colour producer): every sample is it */
+    KF_SOLID       = 1u << 10, /* KF_RECT and the source is one 1x1 packed texel (colour producer): every sample is it */
+    KF_RED_ONLY    = 1u << 12  /* fast kernel: planar draw into a key surface without colour adjustments: only red and
+                                  alpha are looked at (image_mixer.cpp:174-183), the Cb plane is not read */
 };
 
 enum KFastClass : int32_t {
@@ -39,6 +41,24 @@ enum KFastClass : int32_t {
     FC_PACKED = 1, /* one 4-channel plane (bgra / rgba / argb / abgr), unit scale */
     FC_PLANAR = 2, /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
     FC_SURFACE = 3 /* KOP_DRAW_SURFACE: a layer / mix temporary composited 1:1 (any blend mode, either keyer) */
+};
+
+/* Which straight-line bodies of the 4-pixels-per-lane kernel run a draw (host: classify_fast). The kernel switches on
+ * these two numbers and nothing else: computing them per op and wave from the flags cost ~40 scalar instructions. */
+enum KFetchBody : int32_t {
+    FB_SURFACE  = 0, /* KOP_DRAW_SURFACE: the source is a register surface */
+    FB_PACKED8  = 1,
+    FB_PACKED16 = 2,
+    FB_PLANAR8  = 3, /* + csx + 2 * csy */
+    FB_PLANAR16 = 7  /* + csx + 2 * csy */
+};
+enum KBlendBody : int32_t {
+    BB_RGBA_SIMPLE  = 0, /* no key, no invert, linear keyer */
+    BB_RGBA_ONE_KEY = 1, /* exactly one key, else like 0 */
+    BB_RGBA_GENERAL = 2,
+    BB_KEY_SIMPLE   = 3, /* into a key surface */
+    BB_KEY_GENERAL  = 4,
+    BB_MODE         = 5  /* a temporary composited with a blend mode */
 };
 
 /* How cghip_composite samples a KOP_DRAW_PLANES source (host classification, cghip_plan.cpp). The two common
@@ -125,6 +145,10 @@ struct KOp {
        numbers like levels 0.1 / 0.9, moved 1 % of 8-bit samples (tests/test_fuzz.py) */
     float lv_range;      /* max_input - min_input */
     float ch_soft_range; /* ch_softness - 1 */
+    /* FC_PLANAR with 16-bit planes, for the kernels of 16-bit frames: sample codes -> colour as one affine map
+       (cghip_kernels.hip: fetch_planar16r): aY, aR, cR, aGr, aGb, cG, aB, cB */
+    float ycoef[8];
+    int32_t fetch_body, blend_body; /* KFetchBody, KBlendBody (fast kernel) */
     KPlane  planes[4];
     KTri    tri[2];
 };

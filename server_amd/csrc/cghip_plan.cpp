@@ -187,10 +187,35 @@ int floor_div256(int64_t v) { return (int)((v >= 0) ? v / 256 : -((-v + 255) / 2
 
 /* Which draws the 4-pixels-per-lane kernel (cghip_composite_fast) can run: unit-scale sources whose texels
  * can be fetched with aligned vector loads, normal blend into the frame or a key surface. */
+static void classify_fast_draw(KOp& op, int frame_w);
 static void classify_fast(KOp& op, int frame_w)
+{
+    classify_fast_draw(op, frame_w);
+    if (op.fast_class == FC_NONE)
+        return;
+    /* the bodies of cghip_composite_fast that run this draw */
+    const bool wide = op.planes[0].bits == 16;
+    op.fetch_body   = op.fast_class == FC_SURFACE  ? (int)FB_SURFACE
+                      : op.fast_class == FC_PACKED ? (wide ? (int)FB_PACKED16 : (int)FB_PACKED8)
+                                                   : (wide ? (int)FB_PLANAR16 : (int)FB_PLANAR8) + op.csx + 2 * op.csy;
+    const bool to_key = op.dst >= KS_KEY0;
+    if (to_key && op.fast_class == FC_PLANAR && !(op.flags & (KF_CHROMA | KF_LEVELS | KF_CSB)))
+        op.flags |= KF_RED_ONLY;
+    const bool lk = op.local_key != KS_NONE, yk = op.layer_key != KS_NONE;
+    const bool plain_keyer = !(op.flags & (KF_INVERT | KF_ADDITIVE));
+    const bool simple = !lk && !yk && plain_keyer;
+    op.blend_body = to_key                ? (simple ? (int)BB_KEY_SIMPLE : (int)BB_KEY_GENERAL)
+                    : op.blend_mode != 0  ? (int)BB_MODE
+                    : simple              ? (int)BB_RGBA_SIMPLE
+                    : plain_keyer && lk != yk ? (int)BB_RGBA_ONE_KEY
+                                          : (int)BB_RGBA_GENERAL;
+}
+static void classify_fast_draw(KOp& op, int frame_w)
 {
     op.fast_class = FC_NONE;
     op.csx = op.csy = 0;
+    op.fetch_body = op.blend_body = 0;
+    op.flags &= ~(uint32_t)KF_RED_ONLY;
     if (op.kind == KOP_DRAW_SURFACE) {
         /* a temporary composited over the frame (image_mixer.cpp:207-225): no loads, so the only requirement is that
            lanes (4 pixels) are wholly inside or outside the box; pixels past the right frame edge are never stored */
@@ -253,6 +278,15 @@ static void classify_fast(KOp& op, int frame_w)
         op.csx        = halfx ? 1 : 0;
         op.csy        = halfy ? 1 : 0;
         op.fast_class = FC_PLANAR;
+        if (p0.bits == 16) { /* shader.frag:441-467 composed with code / 65535 and / 255, rounded once from double */
+            const bool   hd = op.flags & KF_IS_HD;
+            const double N = 65535.0, y0 = 1.164 * 16.0;
+            const double krr = hd ? 1.793 : 1.596, kgr = hd ? 0.534 : 0.813, kgb = hd ? 0.213 : 0.391, kbb = hd ? 2.115 : 2.018;
+            const double k[8] = {1.164 / N, krr / N, -(y0 + krr * 128.0) / 255.0, -kgr / N, -kgb / N,
+                                 (-y0 + (kgr + kgb) * 128.0) / 255.0, kbb / N, -(y0 + kbb * 128.0) / 255.0};
+            for (int i = 0; i < 8; ++i)
+                op.ycoef[i] = (float)k[i];
+        }
     }
 }
 

@@ -27,6 +27,7 @@ class KOp(C.Structure):
         ("ch_spill_saturation", C.c_float),
         ("fast_class", C.c_int32), ("ch_inv_spill", C.c_float), ("ch_inv_soft", C.c_float), ("sample_class", C.c_int32),
         ("csx", C.c_int32), ("csy", C.c_int32), ("lv_range", C.c_float), ("ch_soft_range", C.c_float),
+        ("ycoef", C.c_float * 8), ("fetch_body", C.c_int32), ("blend_body", C.c_int32),
         ("planes", KPlane * 4), ("tri", KTri * 2),
     ]
 
