@@ -228,6 +228,11 @@ def main():
     import scenes as S
     import server_amd as A
 
+    # torch (the barrier / synchronize plumbing) is imported and its HIP state initialised HERE, before any phase that is
+    # measured or that conditions the GPU: on a fresh box the first `import torch` pages in for many seconds, and when
+    # that happened inside the first device_sync(), between the warmup steps and the timed region, the GPU sat idle for
+    # that long and the 20 timed launches that followed ran 0.21 -> 0.26 ms (the second process on the same box: 0.21).
+    device_sync()
     ndev = A.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the mixer has no CPU fallback)")
@@ -255,6 +260,11 @@ def main():
 
     alg_bytes = S.algorithmic_bytes(scene)
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    srt = sorted(kernel_ms)
+    tenth = max(1, len(kernel_ms) // 10)
+    launch_stats = {"n": len(kernel_ms), "min": srt[0], "median": srt[len(srt) // 2], "p95": srt[min(len(srt) - 1, int(0.95 * len(srt)))],
+                    "max": srt[-1], "first_decile_mean": sum(kernel_ms[:tenth]) / tenth,
+                    "last_decile_mean": sum(kernel_ms[-tenth:]) / tenth}
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
     if ncha > 1:
         # launches of different channels overlap on the GPU, so a launch's own duration says little: price the GPU's
@@ -271,26 +281,25 @@ def main():
         ch.close()
 
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # HBM traffic and VALU instruction count per launch are NOT measured in this run: they come from the committed
+        # rocprofv3 --pmc passes of the same command (profiles/collect.sh); the line names the files
+        def committed(name):
+            path = os.path.join(ROOT, "profiles", name)
             try:
-                traffic = json.load(open(pmc)).get(args.workload)
+                d = json.load(open(path))
+                return d.get(args.workload), d.get("source", "profiles/" + name)
             except Exception:
-                traffic = None
-        # the vector-ALU side of the same launch: instruction count from the committed PMC pass,
-        # duration measured live; peak = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz
+                return None, None
+        traffic, traffic_source = committed("pmc_traffic.json")
+        n_valu, valu_source = committed("pmc_valu.json")
         valu = None
-        pv = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
-        if os.path.exists(pv) and args.workload == "config3_16bit":
-            try:
-                n_valu = json.load(open(pv)).get("SQ_INSTS_VALU")
-                peak = 1024 * 2.4e9 / 2 / 1e9
-                ach = n_valu / (avg_kernel_ms * 1e-3) / 1e9
-                valu = {"wave_instr_per_launch": n_valu, "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
-                        "frac": ach / peak, "note": "kernel is VALU-issue bound; see DESIGN.md section 4"}
-            except Exception:
-                valu = None
+        if n_valu:
+            # the vector-ALU side of the same launch: duration measured live;
+            # peak = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz
+            peak = 1024 * 2.4e9 / 2 / 1e9
+            ach = n_valu / (avg_kernel_ms * 1e-3) / 1e9
+            valu = {"wave_instr_per_launch": n_valu, "source": valu_source, "achieved": ach, "peak": peak,
+                    "unit": "G wave-instr/s", "frac": ach / peak, "note": "see DESIGN.md section 4"}
         line = {
             "metric": "composited frames/s per GPU (2160p, 16 layers) + % of HBM roofline",
             "value": whole_job_value(world * ncha, args.steps, dt),
@@ -309,10 +318,10 @@ def main():
                 sum(1 for o in scene["ops"] if o[0] == "visit"), scene["bits"]),
                 "channels_per_gpu": ncha, "frames_in_flight": 2, "settle_s": args.settle, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": {"config4": "cghip_composite_fast_full<%d>", "config2": "cghip_composite<%d>"}.get(
                              args.workload, "cghip_composite_fast<%d>") % scene["bits"],
-                         "avg_kernel_ms": avg_kernel_ms,
+                         "avg_kernel_ms": avg_kernel_ms, "launch_ms": launch_stats,
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
             "cpu_baseline": cpu,
             "end_to_end_fps": e2e,

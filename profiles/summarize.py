@@ -56,11 +56,14 @@ traffic = {
             "2/4/8 B per lane, so the x2 figure is an upper bound: raw <= true <= x2). WRITE_SIZE equals the frame size.",
 }
 json.dump(traffic, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
-json.dump({workload: traffic["traffic_bytes_per_launch"]}, open(os.path.join(dst, "pmc_traffic.json"), "w"))
+json.dump({workload: traffic["traffic_bytes_per_launch"], "source": "profiles/%s_pmc_traffic.json" % tag},
+          open(os.path.join(dst, "pmc_traffic.json"), "w"))
 
 v, _ = counters("valu")
 v["kernel"] = kernel
 v["note"] = ("per launch, summed over the chip; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles; "
              "GRBM_GUI_ACTIVE is summed over the 8 XCDs (divide by 8 for shader cycles per launch)")
 json.dump(v, open(os.path.join(dst, tag + "_pmc_valu.json"), "w"), indent=1)
+json.dump({workload: v.get("SQ_INSTS_VALU"), "source": "profiles/%s_pmc_valu.json" % tag},
+          open(os.path.join(dst, "pmc_valu.json"), "w"))
 print(json.dumps({"traffic": traffic["traffic_bytes_per_launch"], "valu": v.get("SQ_INSTS_VALU")}))
