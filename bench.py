@@ -287,7 +287,7 @@ def main():
             path = os.path.join(ROOT, "profiles", name)
             try:
                 d = json.load(open(path))
-                return d.get(args.workload), d.get("source", "profiles/" + name)
+                return d.get(args.workload), d.get("sources", {}).get(args.workload, "profiles/" + name)
             except Exception:
                 return None, None
         traffic, traffic_source = committed("pmc_traffic.json")

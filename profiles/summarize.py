@@ -56,14 +56,25 @@ traffic = {
             "2/4/8 B per lane, so the x2 figure is an upper bound: raw <= true <= x2). WRITE_SIZE equals the frame size.",
 }
 json.dump(traffic, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
-json.dump({workload: traffic["traffic_bytes_per_launch"], "source": "profiles/%s_pmc_traffic.json" % tag},
-          open(os.path.join(dst, "pmc_traffic.json"), "w"))
+def merge(name, value, source):
+    """profiles/<name>: workload -> latest per-launch figure (+ which file it came from), what bench.py looks up"""
+    path = os.path.join(dst, name)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        d = {}
+    d[workload] = value
+    d.setdefault("sources", {})[workload] = source
+    d.pop("source", None)
+    json.dump(d, open(path, "w"), indent=1)
+
+
+merge("pmc_traffic.json", traffic["traffic_bytes_per_launch"], "profiles/%s_pmc_traffic.json" % tag)
 
 v, _ = counters("valu")
 v["kernel"] = kernel
 v["note"] = ("per launch, summed over the chip; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles; "
              "GRBM_GUI_ACTIVE is summed over the 8 XCDs (divide by 8 for shader cycles per launch)")
 json.dump(v, open(os.path.join(dst, tag + "_pmc_valu.json"), "w"), indent=1)
-json.dump({workload: v.get("SQ_INSTS_VALU"), "source": "profiles/%s_pmc_valu.json" % tag},
-          open(os.path.join(dst, "pmc_valu.json"), "w"))
+merge("pmc_valu.json", v.get("SQ_INSTS_VALU"), "profiles/%s_pmc_valu.json" % tag)
 print(json.dumps({"traffic": traffic["traffic_bytes_per_launch"], "valu": v.get("SQ_INSTS_VALU")}))

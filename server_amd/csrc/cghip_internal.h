@@ -103,6 +103,10 @@ struct segment {
     bool     full = false;         /* touches RGBA1 / RGBA2 */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
     int      gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0; /* pixel box the launch covers */
+    /* op masks per band of the frame (KSpill::masks): offset into frame_plan::masks, in uint64 */
+    size_t   mask_off = 0;
+    int      ncols = 0, nrows = 0, nchunks = 0, col_shift = 6;
+    bool     dense = false; /* every op is in every band */
 };
 
 struct frame_plan {
@@ -112,6 +116,7 @@ struct frame_plan {
     bool             full = false; /* needs the RGBA1/RGBA2 register surfaces */
     bool             fast = false; /* every draw qualifies for cghip_composite_fast (then there is one segment) */
     std::vector<cghip_plane*> planes; /* every plane referenced by an emitted op */
+    std::vector<uint64_t>     masks;  /* the segments' op masks; uploaded behind the ops */
 };
 
 /* image_renderer / image_kernel host logic -> KOp list. Pure host code (no HIP calls). */

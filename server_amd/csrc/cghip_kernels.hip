@@ -1062,6 +1062,16 @@ DEV bool xcd_block(const KSpill& sp, unsigned& bx, unsigned& by)
     return true;
 }
 
+/* the ops of chunk `chunk` (64 ops) that can touch the wave's band of the frame, as a bit mask (KSpill::masks) */
+DEV uint64_t band_ops(const KSpill& sp, int chunk, int mstride, int mcol, int mrow, int nops)
+{
+    if (sp.dense) {
+        const int n = nops - 64 * chunk;
+        return n >= 64 ? ~0ull : ((1ull << (n > 0 ? n : 0)) - 1ull);
+    }
+    return sp.masks[chunk * mstride + mcol] & sp.masks[chunk * mstride + sp.ncols + mrow];
+}
+
 /* General compositor: one output pixel per lane (one wave = 64 consecutive pixels of a row, one
  * workgroup = 4 rows). FULL = false drops the two extra RGBA surfaces (layer / mix temporaries) from the
  * register file: the host picks it when the frame has only normal-blend, non-mix layers. Surfaces are
@@ -1093,7 +1103,12 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
 
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
-    for (int n = 0; n < nops && row_live; ++n) {
+    /* only the ops that can touch this wave's band of the frame (KSpill::masks, host: op_masks) */
+    const int       mcol = __builtin_amdgcn_readfirstlane(x) >> sp.col_shift, mrow = y >> 2;
+    const int       mstride = sp.ncols + sp.nrows;
+    for (int chunk = 0; chunk < sp.nchunks && row_live; ++chunk)
+    for (uint64_t todo = band_ops(sp, chunk, mstride, mcol, mrow, nops); todo != 0; todo &= todo - 1) {
+        const int  n   = chunk * 64 + __builtin_ctzll(todo);
         const KOp& op  = ops[__builtin_amdgcn_readfirstlane(n)]; /* n is uniform; say so (see dispatch_mode) */
         const HotG h   = load_hot_g(op);
         const bool clr = h.kind == KOP_CLEAR;
@@ -1709,7 +1724,12 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
     }
     const bool row_live = !((field_mode == 1 && (y & 1) != 0) || (field_mode == 2 && (y & 1) != 1));
 
-    for (int n = 0; n < nops && row_live; ++n) {
+    /* only the ops that can touch this wave's band of the frame (KSpill::masks, host: op_masks) */
+    const int mcol = __builtin_amdgcn_readfirstlane(px0) >> sp.col_shift, mrow = y >> 2;
+    const int mstride = sp.ncols + sp.nrows;
+    for (int chunk = 0; chunk < sp.nchunks && row_live; ++chunk)
+    for (uint64_t todo = band_ops(sp, chunk, mstride, mcol, mrow, nops); todo != 0; todo &= todo - 1) {
+        const int   n   = chunk * 64 + __builtin_ctzll(todo);
         const KOp&  op  = ops[__builtin_amdgcn_readfirstlane(n)]; /* n is uniform; say so (see dispatch_mode) */
         const HotOp h   = load_hot(op);
         const bool  clr = h.kind == KOP_CLEAR;
@@ -1976,6 +1996,10 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
 {
     constexpr int FB = CGHIP_FRAME_BITS;
     if (gw <= 0 || gh <= 0 || sp->gx0 < 0 || sp->gy0 < 0 || sp->gx0 + gw > W || sp->gy0 + gh > H)
+        return hipErrorInvalidValue;
+    /* the op masks must cover the frame in the band geometry this kernel indexes them with, and every op */
+    if (!sp->masks || sp->col_shift != (fast ? 8 : 6) || sp->ncols != ((W - 1) >> sp->col_shift) + 1 ||
+        sp->nrows != ((H - 1) >> 2) + 1 || sp->nchunks < 1 || sp->nchunks * 64 < nops)
         return hipErrorInvalidValue;
     KSpill s = *sp;
     dim3   block(256);

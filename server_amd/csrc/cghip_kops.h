@@ -97,6 +97,12 @@ struct KSpill {
     uint32_t store_mask; /* surfaces to write after the last op */
     int32_t  gx0, gy0;
     int32_t  nbx, nby;   /* workgroups per row of the launch and rows of workgroups (set by the launcher, see xcd_block) */
+    /* Which ops of this launch can touch which part of the frame (host: cghip_plan.cpp, op_masks): bit i of
+       masks[chunk * (ncols + nrows) + col] & masks[chunk * (ncols + nrows) + ncols + row] is set iff op 64 * chunk + i
+       has pixels in column band `col` (x >> col_shift) and in row band `row` (y >> 2). A wave walks only those ops. */
+    const uint64_t* masks;
+    int32_t  ncols, nrows, nchunks, col_shift;
+    int32_t  dense; /* every op is in every band (full-screen stacks): the table is not read */
 };
 
 struct KPlane {

@@ -716,6 +716,53 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
     }
 }
 
+/* Per launch: which of its ops can touch which band of the frame. The kernels used to walk the whole op list in
+ * every wave and cull by box there; a wave of a 1080p frame with eight scaled boxes paid the scalar set-up of every op
+ * (~100 scalar instructions each, on a scalar unit shared by four SIMDs) to find that six of them are elsewhere.
+ * Column bands are one wave wide (64 pixels; 256 in the 4-pixels-per-lane kernel), row bands one workgroup high (4 rows).
+ * CLEARs are in every band (they reset a register surface wherever it is used). */
+static void op_masks(const cghip_format& fmt, frame_plan* out)
+{
+    out->masks.clear();
+    for (segment& sg : out->segments) {
+        sg.col_shift = sg.fast ? 8 : 6;
+        sg.ncols     = ((fmt.width - 1) >> sg.col_shift) + 1;
+        sg.nrows     = ((fmt.height - 1) >> 2) + 1;
+        sg.nchunks   = std::max(1, (sg.count + 63) / 64);
+        sg.mask_off  = out->masks.size();
+        const size_t stride = (size_t)sg.ncols + (size_t)sg.nrows;
+        out->masks.resize(out->masks.size() + stride * (size_t)sg.nchunks, 0);
+        uint64_t* base = out->masks.data() + sg.mask_off;
+        for (int i = 0; i < sg.count; ++i) {
+            const KOp&     o   = out->ops[(size_t)(sg.first + i)];
+            uint64_t*      m   = base + stride * (size_t)(i / 64);
+            const uint64_t bit = 1ull << (i % 64);
+            int            c0 = 0, c1 = sg.ncols - 1, r0 = 0, r1 = sg.nrows - 1;
+            if (o.kind != KOP_CLEAR) {
+                if (o.x0 >= o.x1 || o.y0 >= o.y1)
+                    continue;
+                c0 = std::max(0, o.x0) >> sg.col_shift, c1 = std::min(sg.ncols - 1, (o.x1 - 1) >> sg.col_shift);
+                r0 = std::max(0, o.y0) >> 2, r1 = std::min(sg.nrows - 1, (o.y1 - 1) >> 2);
+            }
+            for (int c = c0; c <= c1; ++c)
+                m[c] |= bit;
+            for (int r = r0; r <= r1; ++r)
+                m[sg.ncols + r] |= bit;
+        }
+        /* every op in every band (full-screen stacks): the kernel then does not read the table at all */
+        sg.dense = true;
+        for (int k = 0; k < sg.nchunks && sg.dense; ++k) {
+            const int      nbits = std::min(64, sg.count - 64 * k);
+            const uint64_t all   = nbits >= 64 ? ~0ull : ((1ull << std::max(0, nbits)) - 1);
+            for (size_t j = 0; j < stride; ++j)
+                if (base[stride * (size_t)k + j] != all) {
+                    sg.dense = false;
+                    break;
+                }
+        }
+    }
+}
+
 int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces, const cghip_draw* draws,
                int ndraws, frame_plan* out)
 {
@@ -844,6 +891,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
             out->fast = false;
     drop_hidden_ops(*fmt, out);
     split_into_segments(*fmt, out);
+    op_masks(*fmt, out);
     return CGHIP_OK;
 }
 

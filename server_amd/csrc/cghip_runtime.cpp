@@ -495,7 +495,8 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     t->dev = dev, t->stream = mixer->stream;
     dev->tickets_live++;
     t->out_bytes = (size_t)format->width * format->height * 4 * (format->bits / 8);
-    t->ops_bytes = std::max<size_t>(plan.ops.size(), 1) * sizeof(KOp);
+    const size_t ops_only = plan.ops.size() * sizeof(KOp), mask_bytes = plan.masks.size() * sizeof(uint64_t);
+    t->ops_bytes = std::max<size_t>(ops_only + mask_bytes, 1); /* the op list, then the segments' op masks */
 #define T_TRY(expr)                                                                                                    \
     do {                                                                                                               \
         int rc__ = (expr);                                                                                             \
@@ -523,12 +524,16 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     /* The op list goes up on a stream of its own, so that it travels while the previous frame of this channel is
        still compositing; on the compositor's stream the copy sat between two launches. The ticket's buffers are its
        own (or from the pool, whose previous user is done), so nothing else orders this copy. */
-    if (!plan.ops.empty()) {
-        std::memcpy(t->h_ops, plan.ops.data(), plan.ops.size() * sizeof(KOp));
+    if (ops_only + mask_bytes > 0) {
+        if (ops_only)
+            std::memcpy(t->h_ops, plan.ops.data(), ops_only);
+        if (mask_bytes)
+            std::memcpy((char*)t->h_ops + ops_only, plan.masks.data(), mask_bytes);
         T_HIP(hipEventCreateWithFlags(&t->ev_ops, hipEventDisableTiming));
-        T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, mixer->ops_stream));
+        T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, ops_only + mask_bytes, hipMemcpyHostToDevice, mixer->ops_stream));
         T_HIP(hipEventRecord(t->ev_ops, mixer->ops_stream));
     }
+    const uint64_t* d_masks = (const uint64_t*)((const char*)t->d_ops + ops_only);
     /* the frame keeps its source planes alive and waits for their uploads (device.cpp:242-262 futures). A still or a
        routed frame is visited tick after tick: once its upload has been seen complete there is nothing to wait for,
        and a 16-layer 4:2:2 frame no longer queues 48 event waits in front of its launch. */
@@ -564,6 +569,8 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
         sp.rgba1 = t->spill[0], sp.rgba2 = t->spill[1], sp.key0 = t->spill[2], sp.key1 = t->spill[3];
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
+        sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
+        sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0;
         T_HIP(cghip_launch_composite((const KOp*)t->d_ops + sg.first, sg.count, t->d_out, format->width, format->height,
                                      format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 : 0, &sp,
                                      sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, t->stream));
@@ -620,6 +627,9 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
         return fail(CGHIP_ERR_INVALID, "device_out must be 16-byte aligned");
     if (plan.ops.size() > CGHIP_NOALLOC_MAX_OPS)
         return fail(CGHIP_ERR_UNSUPPORTED, "frame has more than CGHIP_NOALLOC_MAX_OPS (256) ops: use cghip_mixer_render_async");
+    const size_t mask_region = 512u << 10; /* the launches' op masks, behind the op list */
+    if (plan.masks.size() * sizeof(uint64_t) > mask_region)
+        return fail(CGHIP_ERR_UNSUPPORTED, "frame is too large or cut too often for cghip_mixer_render_noalloc's op-mask region");
     if (dev->gpu < 0 || dev->gpu >= 64)
         return fail(CGHIP_ERR_UNSUPPORTED, "gpu index beyond the scratch table");
 
@@ -628,7 +638,8 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
     size_t cap  = 0;
     CGHIP_TRY_HIP(cghip_scratch_address(dev->gpu, &base, &cap));
     /* lay the hand-over surfaces out behind the op list; refuse what does not fit */
-    const size_t ops_region = round_up((size_t)CGHIP_NOALLOC_MAX_OPS * sizeof(KOp), 256);
+    const size_t ops_only   = round_up((size_t)CGHIP_NOALLOC_MAX_OPS * sizeof(KOp), 256);
+    const size_t ops_region = ops_only + mask_region;
     size_t       off        = ops_region;
     void*        spill[4]   = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; ++i)
@@ -655,6 +666,10 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
     }
     if (!plan.ops.empty()) /* pageable source: the runtime stages it itself; ordered on the compositor's stream */
         CGHIP_TRY_HIP(hipMemcpyAsync(base, plan.ops.data(), plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, st));
+    const uint64_t* d_masks = (const uint64_t*)((const char*)base + ops_only);
+    if (!plan.masks.empty())
+        CGHIP_TRY_HIP(hipMemcpyAsync((void*)d_masks, plan.masks.data(), plan.masks.size() * sizeof(uint64_t),
+                                     hipMemcpyHostToDevice, st));
     int        launches = 0;
     hipError_t e        = hipSuccess;
     for (const segment& sg : plan.segments) {
@@ -662,6 +677,8 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
         sp.rgba1 = spill[0], sp.rgba2 = spill[1], sp.key0 = spill[2], sp.key1 = spill[3];
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
+        sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
+        sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0;
         e = cghip_launch_composite((const KOp*)base + sg.first, sg.count, device_out, format->width, format->height,
                                    format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 : 0, &sp,
                                    sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, st);
