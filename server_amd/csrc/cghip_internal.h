@@ -39,6 +39,12 @@ struct cghip_device {
     int         gpu = 0;
     std::string name;
     hipStream_t upload_stream = nullptr; /* H2D of producer planes; shared by all producer threads */
+    hipStream_t peer_stream   = nullptr; /* device-to-device copies of routed planes INTO this device: a 16.6 MB plane
+                                            arriving over xGMI must not queue behind this GPU's PCIe uploads */
+    /* peer access from this GPU to the memory of GPU k, asked for lazily at the first routed plane from k
+       (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess): 0 not asked, 1 granted (copies go device to device over
+       xGMI), -1 refused (the runtime stages the copy through host memory), 2 the same physical GPU */
+    std::map<int, int> peer_access;
     std::mutex  mu;
     cghip::pool device_pool; /* hipMalloc'd blocks: planes, frame outputs, op lists */
     cghip::pool pinned_pool; /* hipHostMalloc'd blocks */

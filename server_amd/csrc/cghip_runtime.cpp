@@ -136,6 +136,11 @@ int cghip_device_create(int gpu_index, cghip_device** out)
     d->gpu          = gpu_index;
     d->name         = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     hipError_t e    = hipStreamCreateWithFlags(&d->upload_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        e = hipStreamCreateWithFlags(&d->peer_stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            (void)hipStreamDestroy(d->upload_stream);
+    }
     if (e != hipSuccess) {
         delete d;
         return fail_hip(e, "hipStreamCreateWithFlags");
@@ -145,6 +150,7 @@ int cghip_device_create(int gpu_index, cghip_device** out)
     e             = cghip_scratch_address(gpu_index, &scratch, nullptr);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(d->upload_stream);
+        (void)hipStreamDestroy(d->peer_stream);
         delete d;
         return fail_hip(e, "hipGetSymbolAddress(scratch)");
     }
@@ -183,6 +189,8 @@ int cghip_device_destroy(cghip_device* dev)
     int rc = cghip_device_gc(dev);
     if (dev->upload_stream)
         (void)hipStreamDestroy(dev->upload_stream);
+    if (dev->peer_stream)
+        (void)hipStreamDestroy(dev->peer_stream);
     delete dev;
     return rc;
 }
@@ -195,12 +203,20 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
     (void)hipSetDevice(dev->gpu);
     (void)hipMemGetInfo(&free_b, &total_b);
     std::lock_guard<std::mutex> g(dev->mu);
+    std::string peers = "{";
+    for (auto& kv : dev->peer_access) {
+        if (peers.size() > 1)
+            peers += ",";
+        peers += "\"" + std::to_string(kv.first) + "\":\"" +
+                 (kv.second == 1 ? "granted" : kv.second == 2 ? "same_gpu" : kv.second == -1 ? "refused" : "unknown") + "\"";
+    }
+    peers += "}";
     int n = snprintf(json, capacity,
                      "{\"gpu\":%d,\"name\":\"%s\",\"hbm_total_bytes\":%zu,\"hbm_free_bytes\":%zu,"
                      "\"device_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"pinned_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld,\"kernel_launches\":%lld,"
-                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld,\"uploads\":%lld,\"upload_bytes\":%lld}",
+                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld,\"uploads\":%lld,\"upload_bytes\":%lld,\"peer_access\":%s}",
                      dev->gpu, dev->name.c_str(), total_b, free_b, dev->device_pool.count_total,
                      dev->device_pool.bytes_total, dev->device_pool.bytes_free, dev->pinned_pool.count_total,
                      dev->pinned_pool.bytes_total, dev->pinned_pool.bytes_free, (long long)dev->planes_live.load(),
@@ -208,7 +224,7 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
                      (long long)dev->frames_rendered.load(), (long long)dev->kernel_launches.load(),
                      (long long)dev->peer_copies.load(),
                      (long long)dev->peer_copy_bytes.load(), (long long)dev->uploads.load(),
-                     (long long)dev->upload_bytes.load());
+                     (long long)dev->upload_bytes.load(), peers.c_str());
     if (n < 0 || (size_t)n >= capacity)
         return fail(CGHIP_ERR_INVALID, "info buffer too small");
     return CGHIP_OK;
@@ -363,12 +379,31 @@ int cghip_plane_peer_copy_async(cghip_device* dst_dev, cghip_plane* src, cghip_p
     if (rc != CGHIP_OK)
         return rc;
     hipError_t e = hipSetDevice(dst_dev->gpu);
+    if (e == hipSuccess) { /* first plane from that GPU: ask for direct access to its memory */
+        std::lock_guard<std::mutex> g(dst_dev->mu);
+        int& st = dst_dev->peer_access[src->dev->gpu];
+        if (st == 0) {
+            if (src->dev->gpu == dst_dev->gpu) {
+                st = 2;
+            } else {
+                int        can = 0;
+                hipError_t pe  = hipDeviceCanAccessPeer(&can, dst_dev->gpu, src->dev->gpu);
+                if (pe == hipSuccess && can) {
+                    pe = hipDeviceEnablePeerAccess(src->dev->gpu, 0);
+                    st = (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) ? 1 : -1;
+                } else {
+                    st = -1;
+                }
+                (void)hipGetLastError(); /* a refusal is not an error: the copy below is then staged by the runtime */
+            }
+        }
+    }
     if (e == hipSuccess)
-        e = hipStreamWaitEvent(dst_dev->upload_stream, src->ready, 0);
+        e = hipStreamWaitEvent(dst_dev->peer_stream, src->ready, 0);
     if (e == hipSuccess)
-        e = hipMemcpyPeerAsync(p->dptr, dst_dev->gpu, src->dptr, src->dev->gpu, src->bytes, dst_dev->upload_stream);
+        e = hipMemcpyPeerAsync(p->dptr, dst_dev->gpu, src->dptr, src->dev->gpu, src->bytes, dst_dev->peer_stream);
     if (e == hipSuccess)
-        e = hipEventRecord(p->ready, dst_dev->upload_stream);
+        e = hipEventRecord(p->ready, dst_dev->peer_stream);
     if (e != hipSuccess) {
         cghip_plane_release(p);
         return fail_hip(e, "peer copy");

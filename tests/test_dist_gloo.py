@@ -19,9 +19,23 @@ def free_port():
     return p
 
 
+import pytest
+
+
 def test_world_size_2_gloo(tmp_path):
+    _run_world_of_2(tmp_path, gpu=False)
+
+
+@pytest.mark.gpu
+def test_world_size_2_gloo_composites_on_the_gpu(tmp_path):
+    """The same job with the ranks' channels compositing on the GPU (two processes share GPU 0 on a one-GPU box) and
+    every frame checked against the oracle."""
+    _run_world_of_2(tmp_path, gpu=True)
+
+
+def _run_world_of_2(tmp_path, gpu):
     out = str(tmp_path / "rank")
-    env = dict(os.environ, CGHIP_DIST_BACKEND="gloo")
+    env = dict(os.environ, CGHIP_DIST_BACKEND="gloo", CGHIP_DIST_GPU="1" if gpu else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
@@ -35,6 +49,8 @@ def test_world_size_2_gloo(tmp_path):
     assert abs(recs[0]["value"] - 2 * 7 / recs[0]["max"]) < 1e-6
     # channel c lives on rank c % world (accelerator.cpp placement), every channel exactly once
     assert recs[0]["channels"] == [0, 2, 4, 6, 8] and recs[1]["channels"] == [1, 3, 5, 7, 9]
+    # every rank drove every channel of its shard through the mixer on every step
+    assert all(x["rendered"] == 7 * 5 and x["mode"] == ("gpu" if gpu else "dry") for x in recs)
 
 
 def test_shard_helpers_single_process():

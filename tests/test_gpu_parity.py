@@ -416,6 +416,47 @@ def test_routed_frame_is_peer_copied_once_per_device(mixer):
         other.close()
 
 
+def test_config5_shape_routed_2160p_layer(mixer):
+    """BASELINE configs[4] in the shape one GPU allows: the config-3 8-bit stack at 2160p whose layer 0 is a ROUTE of a
+    frame that lives on another device (a private device object on GPU 0 stands in for the neighbour GPU: to the host
+    code and the C ABI it is a foreign device, the copy is hipMemcpyPeerAsync on the destination's peer stream). The
+    frame must equal the unrouted one bit for bit, and a tick moves exactly one 4:2:2 8-bit 2160p layer, 16 588 800
+    bytes, once - however many ticks show it."""
+    import server_amd as A
+    sc = S.config3(bits=8)
+    W, H = sc["width"], sc["height"]
+    cache = {}
+    want = S.run_product(sc, mixer=mixer, planes_cache=cache)
+    visits = [op for op in sc["ops"] if op[0] == "visit"]
+    other = A.Mixer(channel_id=8, gpu=-100)  # the neighbour GPU's channel
+    routed = None
+    try:
+        routed = other.create_frame(visits[0][1]["fmt"], S._planes(visits[0][1], cache))  # lives on `other`'s device
+        before = mixer.device_info()
+        for tick in range(2):
+            first = True
+            for op in sc["ops"]:
+                if op[0] == "push":
+                    mixer.push(A.default_transform(**op[1]))
+                elif op[0] == "visit" and first:
+                    mixer.visit_frame(routed)
+                    first = False
+                elif op[0] == "visit":
+                    mixer.visit(op[1]["fmt"], S._planes(op[1], cache), op[1].get("coords"))
+                else:
+                    mixer.pop()
+            got = mixer.get(mixer.render_async(W, H))
+            assert np.array_equal(got, want), S.diff_stats(got, want)
+        after = mixer.device_info()
+        assert after["peer_copy_bytes"] - before["peer_copy_bytes"] == 16_588_800  # once, not once per tick
+        assert after["peer_copies"] - before["peer_copies"] == 3
+        assert after["peer_access"].get("0") == "same_gpu", after["peer_access"]  # asked for, and answered
+    finally:
+        if routed is not None:
+            other.destroy_frame(routed)
+        other.close()
+
+
 def test_uyvy_bytes_are_uploaded_once(mixer):
     """SURVEY 8f rank 2 (av_util.cpp:163-171, TODO at :45): uyvy binds the same bytes as RG8 w x h and RGBA8 w/2 x h;
     the frame factory uploads them once and aliases the second plane. Output parity of uyvy is covered by the
