@@ -45,9 +45,19 @@ struct cghip_device {
        (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess): 0 not asked, 1 granted (copies go device to device over
        xGMI), -1 refused (the runtime stages the copy through host memory), 2 the same physical GPU */
     std::map<int, int> peer_access;
-    std::mutex  mu;
+    std::mutex  mu;          /* peer_access and the counters' snapshot */
+    std::mutex  mu_dev, mu_pin, mu_ev; /* one lock per pool: 32 channel threads and the producers' upload threads take
+                                          device blocks, pinned blocks and events independently */
     cghip::pool device_pool; /* hipMalloc'd blocks: planes, frame outputs, op lists */
     cghip::pool pinned_pool; /* hipHostMalloc'd blocks */
+    /* hipEvents are pooled like memory: a frame used to create and destroy three or four of them. EV_TIMED: start /
+       stop of the compositor (elapsed time is read); EV_DONE: completion a thread sleeps on (blocking sync instead of
+       the default busy wait: 32 channel threads of one GPU would each spin a core); EV_ORDER: stream-to-stream order */
+    enum { EV_TIMED = 0, EV_DONE = 1, EV_ORDER = 2, EV_KINDS = 3 };
+    std::vector<hipEvent_t> event_pool[EV_KINDS];
+    std::atomic<int64_t>    events_created{0};
+    int  event_get(int kind, hipEvent_t* out);
+    void event_put(int kind, hipEvent_t ev);
     std::atomic<int64_t> planes_live{0}, tickets_live{0}, frames_rendered{0}, kernel_launches{0}, mixers{0};
     std::atomic<int64_t> peer_copies{0}, peer_copy_bytes{0}; /* routed planes copied INTO this device */
     std::atomic<int64_t> uploads{0}, upload_bytes{0};        /* host-to-device plane uploads */

@@ -8,6 +8,7 @@
  * byte size like the reference's (device.cpp:194-233) and grow instead of blocking.
  */
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "cghip_internal.h"
@@ -36,11 +37,40 @@ using namespace cghip;
 
 /* ------------------------------------------------------------------ pools */
 
+int cghip_device::event_get(int kind, hipEvent_t* out)
+{
+    {
+        std::lock_guard<std::mutex> g(mu_ev);
+        if (!event_pool[kind].empty()) {
+            *out = event_pool[kind].back();
+            event_pool[kind].pop_back();
+            return CGHIP_OK;
+        }
+    }
+    CGHIP_TRY_HIP(hipSetDevice(gpu));
+    /* CGHIP_EVENT_WAIT=spin: busy-waiting completion events (lowest wake-up latency, one core per waiting thread) */
+    static const bool spin = [] { const char* v = getenv("CGHIP_EVENT_WAIT"); return v && std::strcmp(v, "spin") == 0; }();
+    const unsigned    block = spin ? 0u : (unsigned)hipEventBlockingSync;
+    const unsigned    flags = kind == EV_TIMED  ? block
+                              : kind == EV_DONE ? (block | hipEventDisableTiming)
+                                                : hipEventDisableTiming;
+    CGHIP_TRY_HIP(hipEventCreateWithFlags(out, flags));
+    events_created++;
+    return CGHIP_OK;
+}
+void cghip_device::event_put(int kind, hipEvent_t ev)
+{
+    if (!ev)
+        return;
+    std::lock_guard<std::mutex> g(mu_ev);
+    event_pool[kind].push_back(ev);
+}
+
 int cghip_device::dev_alloc(size_t bytes, void** out)
 {
     bytes = round_up(bytes ? bytes : 1, 256);
     {
-        std::lock_guard<std::mutex> g(mu);
+        std::lock_guard<std::mutex> g(mu_dev);
         auto                        it = device_pool.free_.find(bytes);
         if (it != device_pool.free_.end()) {
             *out = it->second;
@@ -51,7 +81,7 @@ int cghip_device::dev_alloc(size_t bytes, void** out)
     }
     CGHIP_TRY_HIP(hipSetDevice(gpu));
     CGHIP_TRY_HIP(hipMalloc(out, bytes));
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<std::mutex> g(mu_dev);
     device_pool.bytes_total += bytes;
     device_pool.count_total++;
     return CGHIP_OK;
@@ -61,7 +91,7 @@ void cghip_device::dev_free(void* p, size_t bytes)
     if (!p)
         return;
     bytes = round_up(bytes ? bytes : 1, 256);
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<std::mutex> g(mu_dev);
     device_pool.free_.emplace(bytes, p);
     device_pool.bytes_free += bytes;
 }
@@ -69,7 +99,7 @@ int cghip_device::pinned_alloc(size_t bytes, void** out)
 {
     bytes = round_up(bytes ? bytes : 1, 4096);
     {
-        std::lock_guard<std::mutex> g(mu);
+        std::lock_guard<std::mutex> g(mu_pin);
         auto                        it = pinned_pool.free_.find(bytes);
         if (it != pinned_pool.free_.end()) {
             *out = it->second;
@@ -80,7 +110,7 @@ int cghip_device::pinned_alloc(size_t bytes, void** out)
     }
     CGHIP_TRY_HIP(hipSetDevice(gpu));
     CGHIP_TRY_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<std::mutex> g(mu_pin);
     pinned_pool.bytes_total += bytes;
     pinned_pool.count_total++;
     return CGHIP_OK;
@@ -90,7 +120,7 @@ void cghip_device::pinned_free(void* p, size_t bytes)
     if (!p)
         return;
     bytes = round_up(bytes ? bytes : 1, 4096);
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<std::mutex> g(mu_pin);
     pinned_pool.free_.emplace(bytes, p);
     pinned_pool.bytes_free += bytes;
 }
@@ -163,15 +193,27 @@ int cghip_device_gc(cghip_device* dev)
     if (!dev)
         return fail(CGHIP_ERR_INVALID, "dev is null");
     std::multimap<size_t, void*> d, p;
+    std::vector<hipEvent_t>      evs;
     {
-        std::lock_guard<std::mutex> g(dev->mu);
+        std::lock_guard<std::mutex> g(dev->mu_dev);
         d.swap(dev->device_pool.free_);
-        p.swap(dev->pinned_pool.free_);
         dev->device_pool.bytes_total -= dev->device_pool.bytes_free;
-        dev->pinned_pool.bytes_total -= dev->pinned_pool.bytes_free;
         dev->device_pool.count_total -= d.size();
+        dev->device_pool.bytes_free = 0;
+    }
+    {
+        std::lock_guard<std::mutex> g(dev->mu_pin);
+        p.swap(dev->pinned_pool.free_);
+        dev->pinned_pool.bytes_total -= dev->pinned_pool.bytes_free;
         dev->pinned_pool.count_total -= p.size();
-        dev->device_pool.bytes_free = dev->pinned_pool.bytes_free = 0;
+        dev->pinned_pool.bytes_free = 0;
+    }
+    {
+        std::lock_guard<std::mutex> g(dev->mu_ev);
+        for (auto& pool : dev->event_pool) {
+            evs.insert(evs.end(), pool.begin(), pool.end());
+            pool.clear();
+        }
     }
     CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
     CGHIP_TRY_HIP(hipDeviceSynchronize());
@@ -179,6 +221,8 @@ int cghip_device_gc(cghip_device* dev)
         (void)hipFree(kv.second);
     for (auto& kv : p)
         (void)hipHostFree(kv.second);
+    for (hipEvent_t e : evs)
+        (void)hipEventDestroy(e);
     return CGHIP_OK;
 }
 
@@ -203,6 +247,8 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
     (void)hipSetDevice(dev->gpu);
     (void)hipMemGetInfo(&free_b, &total_b);
     std::lock_guard<std::mutex> g(dev->mu);
+    std::lock_guard<std::mutex> g1(dev->mu_dev);
+    std::lock_guard<std::mutex> g2(dev->mu_pin);
     std::string peers = "{";
     for (auto& kv : dev->peer_access) {
         if (peers.size() > 1)
@@ -216,7 +262,7 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
                      "\"device_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"pinned_pool\":{\"blocks\":%zu,\"bytes\":%zu,\"bytes_pooled\":%zu},"
                      "\"planes_live\":%lld,\"tickets_live\":%lld,\"mixers\":%lld,\"frames_rendered\":%lld,\"kernel_launches\":%lld,"
-                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld,\"uploads\":%lld,\"upload_bytes\":%lld,\"peer_access\":%s}",
+                     "\"peer_copies\":%lld,\"peer_copy_bytes\":%lld,\"uploads\":%lld,\"upload_bytes\":%lld,\"events_created\":%lld,\"peer_access\":%s}",
                      dev->gpu, dev->name.c_str(), total_b, free_b, dev->device_pool.count_total,
                      dev->device_pool.bytes_total, dev->device_pool.bytes_free, dev->pinned_pool.count_total,
                      dev->pinned_pool.bytes_total, dev->pinned_pool.bytes_free, (long long)dev->planes_live.load(),
@@ -224,7 +270,7 @@ int cghip_device_info(cghip_device* dev, char* json, size_t capacity)
                      (long long)dev->frames_rendered.load(), (long long)dev->kernel_launches.load(),
                      (long long)dev->peer_copies.load(),
                      (long long)dev->peer_copy_bytes.load(), (long long)dev->uploads.load(),
-                     (long long)dev->upload_bytes.load(), peers.c_str());
+                     (long long)dev->upload_bytes.load(), (long long)dev->events_created.load(), peers.c_str());
     if (n < 0 || (size_t)n >= capacity)
         return fail(CGHIP_ERR_INVALID, "info buffer too small");
     return CGHIP_OK;
@@ -283,11 +329,11 @@ static int plane_new(cghip_device* dev, int width, int height, int channels, int
         delete p;
         return rc;
     }
-    hipError_t e = hipEventCreateWithFlags(&p->ready, hipEventDisableTiming);
-    if (e != hipSuccess) {
+    rc = dev->event_get(cghip_device::EV_ORDER, &p->ready);
+    if (rc != CGHIP_OK) {
         dev->dev_free(p->dptr, p->bytes + 16);
         delete p;
-        return fail_hip(e, "hipEventCreateWithFlags");
+        return rc;
     }
     dev->planes_live++;
     *out = p;
@@ -344,7 +390,7 @@ int cghip_plane_release(cghip_plane* plane)
            every reader through the ready event chain, or after the ticket that retained the plane */
         if (plane->ready) {
             (void)hipEventSynchronize(plane->ready);
-            (void)hipEventDestroy(plane->ready);
+            plane->dev->event_put(cghip_device::EV_ORDER, plane->ready);
         }
         plane->dev->dev_free(plane->dptr, plane->bytes + 16);
         plane->dev->planes_live--;
@@ -486,18 +532,23 @@ int cghip_mixer_destroy(cghip_mixer* mixer)
     return CGHIP_OK;
 }
 
-static void ticket_free(cghip_ticket* t)
+static void ticket_free(cghip_ticket* t, hipStream_t also_drain = nullptr)
 {
     cghip_device* dev = t->dev;
-    if (t->ev_done) {
-        (void)hipEventSynchronize(t->ev_done);
-        (void)hipEventDestroy(t->ev_done);
-    } else if (t->ev_stop) {
-        (void)hipEventSynchronize(t->ev_stop);
+    if (also_drain) { /* error path of render_async: copies and launches may already be queued on both streams, and
+                         the events that normally order the release have not been recorded */
+        (void)hipStreamSynchronize(also_drain);
+        (void)hipStreamSynchronize(t->stream);
     }
-    if (t->ev_start) (void)hipEventDestroy(t->ev_start);
-    if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
-    if (t->ev_ops) (void)hipEventDestroy(t->ev_ops);
+    if (t->ev_done)
+        (void)hipEventSynchronize(t->ev_done);
+    else if (t->ev_stop)
+        (void)hipEventSynchronize(t->ev_stop);
+    /* all four are complete now (ev_ops and ev_start precede ev_stop on the stream): back to the pool */
+    dev->event_put(cghip_device::EV_DONE, t->ev_done);
+    dev->event_put(cghip_device::EV_TIMED, t->ev_start);
+    dev->event_put(cghip_device::EV_TIMED, t->ev_stop);
+    dev->event_put(cghip_device::EV_ORDER, t->ev_ops);
     dev->dev_free(t->d_out, t->out_bytes);
     dev->dev_free(t->d_ops, t->ops_bytes);
     for (int i = 0; i < 4; ++i)
@@ -536,7 +587,7 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     do {                                                                                                               \
         int rc__ = (expr);                                                                                             \
         if (rc__ != CGHIP_OK) {                                                                                        \
-            ticket_free(t);                                                                                            \
+            ticket_free(t, mixer->ops_stream);                                                                         \
             return rc__;                                                                                               \
         }                                                                                                              \
     } while (0)
@@ -544,17 +595,17 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     do {                                                                                                               \
         hipError_t e__ = (expr);                                                                                       \
         if (e__ != hipSuccess) {                                                                                       \
-            ticket_free(t);                                                                                            \
+            ticket_free(t, mixer->ops_stream);                                                                         \
             return fail_hip(e__, #expr);                                                                               \
         }                                                                                                              \
     } while (0)
     T_TRY(dev->dev_alloc(t->out_bytes, &t->d_out));
     T_TRY(dev->dev_alloc(t->ops_bytes, &t->d_ops));
     T_TRY(dev->pinned_alloc(t->ops_bytes, &t->h_ops));
-    T_HIP(hipEventCreate(&t->ev_start));
-    T_HIP(hipEventCreate(&t->ev_stop));
+    T_TRY(dev->event_get(cghip_device::EV_TIMED, &t->ev_start));
+    T_TRY(dev->event_get(cghip_device::EV_TIMED, &t->ev_stop));
     if (flags & CGHIP_RENDER_READBACK) /* without a readback the frame is done when its last launch is: ev_stop */
-        T_HIP(hipEventCreateWithFlags(&t->ev_done, hipEventDisableTiming));
+        T_TRY(dev->event_get(cghip_device::EV_DONE, &t->ev_done));
 
     /* The op list goes up on a stream of its own, so that it travels while the previous frame of this channel is
        still compositing; on the compositor's stream the copy sat between two launches. The ticket's buffers are its
@@ -564,7 +615,7 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
             std::memcpy(t->h_ops, plan.ops.data(), ops_only);
         if (mask_bytes)
             std::memcpy((char*)t->h_ops + ops_only, plan.masks.data(), mask_bytes);
-        T_HIP(hipEventCreateWithFlags(&t->ev_ops, hipEventDisableTiming));
+        T_TRY(dev->event_get(cghip_device::EV_ORDER, &t->ev_ops));
         T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, ops_only + mask_bytes, hipMemcpyHostToDevice, mixer->ops_stream));
         T_HIP(hipEventRecord(t->ev_ops, mixer->ops_stream));
     }

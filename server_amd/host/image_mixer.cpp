@@ -18,6 +18,7 @@ extern "C" int cghip_debug_plane_stub(int width, int height, int channels, int b
 #include <functional>
 #include <map>
 #include <mutex>
+#include <set>
 #include <stdexcept>
 
 namespace caspar {
@@ -117,15 +118,49 @@ plane_ptr own(cghip_plane* p)
  * device gets a device-to-device copy over xGMI (cghip_plane_peer_copy_async), and the copy is cached HERE, per
  * destination device, so that N routes of one frame onto a GPU (or N ticks showing the same still) copy it once. The
  * cache dies with the frame. */
-struct uploaded
+struct uploaded;
+/* The opaques this accelerator made and that are still alive. const_frame::opaque() is type-erased (boost::any in the
+ * reference, where the pointer form of any_cast answers the question); here a foreign opaque must be told from ours
+ * WITHOUT touching the pointee, so visit() looks the pointer up. */
+struct uploaded_registry
 {
-    /* declared first = destroyed last: planes return their memory to their device's pools on release */
+    std::mutex                mu;
+    std::set<const uploaded*> live;
+    static uploaded_registry& get()
+    {
+        static uploaded_registry r;
+        return r;
+    }
+    void add(const uploaded* u)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        live.insert(u);
+    }
+    void remove(const uploaded* u)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        live.erase(u);
+    }
+    bool ours(const void* p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        return live.count(static_cast<const uploaded*>(p)) != 0;
+    }
+};
+
+struct uploaded : std::enable_shared_from_this<uploaded>
+{
+    /* declared first = destroyed last: planes return their memory to their device's pools on release, and the pinned
+       buffers an upload is still reading (`sources`) outlive the planes, whose release waits for that upload */
     std::shared_ptr<device>                home_keep;   /* the device the planes live on */
-    std::shared_ptr<device>                origin_keep; /* routed copy: its planes retain the source planes */
-    std::vector<plane_ptr>                 planes;
+    std::shared_ptr<uploaded>              origin_keep; /* routed copy: the frame it was copied from, with its pinned
+                                                           buffers, until the copy is gone */
     std::vector<array<const std::uint8_t>> sources;
-    int                                    magic = 0x48495031; /* "HIP1": recognise our own opaque */
+    std::vector<plane_ptr>                 planes;
     cghip_device*                          home  = nullptr;
+    uploaded() { uploaded_registry::get().add(this); }
+    ~uploaded() { uploaded_registry::get().remove(this); }
+    uploaded(const uploaded&) = delete;
     std::mutex                                                        route_mu;
     std::vector<std::pair<cghip_device*, std::shared_ptr<uploaded>>> routed;
 
@@ -139,7 +174,7 @@ struct uploaded
         auto copy       = std::make_shared<uploaded>();
         copy->home      = dst;
         copy->home_keep   = dst_dev;
-        copy->origin_keep = home_keep;
+        copy->origin_keep = shared_from_this();
         for (auto& pl : planes) {
             cghip_plane* out = nullptr; /* the copy retains its source plane (cghip.h) */
             check(cghip_plane_peer_copy_async(dst, pl.get(), &out), "cghip_plane_peer_copy_async");
@@ -425,8 +460,10 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
         it.geometry  = frame.geometry();
 
         /* pointer-form any_cast: tolerate empty / foreign opaque (SURVEY 8b ownership) */
-        auto up = std::static_pointer_cast<uploaded>(frame.opaque());
-        if (up && up->magic == 0x48495031 && up->planes.size() == it.pix_desc.planes.size()) {
+        std::shared_ptr<uploaded> up;
+        if (frame.opaque() && uploaded_registry::get().ours(frame.opaque().get()))
+            up = std::static_pointer_cast<uploaded>(frame.opaque());
+        if (up && up->planes.size() == it.pix_desc.planes.size()) {
             /* a routed frame whose planes live on another device is copied over once per destination device */
             it.textures = (dev_ && up->home && up->home != dev_->handle()) ? up->on_device(dev_) : up;
         } else {
