@@ -113,6 +113,9 @@ typedef struct cghip_draw {
  * field renders themselves (modules/decklink/consumer/decklink_consumer.cpp:293-308,
  * modules/newtek/consumer/newtek_ndi_consumer.cpp:135-140). */
 #define CGHIP_RENDER_FIELD_ROWS_ONLY 0x2u
+/* No hipEvent pair around the frame's launches: cghip_ticket_kernel_ms reports 0. A channel that does not feed a
+ * diagnostics graph saves one runtime call and one queue packet per frame. */
+#define CGHIP_RENDER_UNTIMED 0x4u
 /* Surface slots one frame's draw list may name (slot 0 = the frame; every key / mix / layer temporary the renderer
  * creates is one more). Slots are bound to the kernel's register surfaces by liveness, so this only bounds the list. */
 #define CGHIP_MAX_SURFACES 1024

@@ -602,22 +602,35 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     T_TRY(dev->dev_alloc(t->out_bytes, &t->d_out));
     T_TRY(dev->dev_alloc(t->ops_bytes, &t->d_ops));
     T_TRY(dev->pinned_alloc(t->ops_bytes, &t->h_ops));
-    T_TRY(dev->event_get(cghip_device::EV_TIMED, &t->ev_start));
+    if (!(flags & CGHIP_RENDER_UNTIMED)) /* one queue packet and one runtime call less per frame */
+        T_TRY(dev->event_get(cghip_device::EV_TIMED, &t->ev_start));
     T_TRY(dev->event_get(cghip_device::EV_TIMED, &t->ev_stop));
     if (flags & CGHIP_RENDER_READBACK) /* without a readback the frame is done when its last launch is: ev_stop */
         T_TRY(dev->event_get(cghip_device::EV_DONE, &t->ev_done));
 
-    /* The op list goes up on a stream of its own, so that it travels while the previous frame of this channel is
-       still compositing; on the compositor's stream the copy sat between two launches. The ticket's buffers are its
-       own (or from the pool, whose previous user is done), so nothing else orders this copy. */
+    /* The op list (a few KB) goes up from pinned memory. A channel that has its GPU to itself sends it on a stream of
+       its own, so that it travels while the previous frame is still compositing (on the compositor's stream the copy
+       sits between two launches: +2 us a frame on BASELINE config 3). With several channels on the GPU the queue never
+       runs dry, and what counts is the number of runtime calls a frame costs its thread, all of which meet in the
+       runtime's queue locks: the copy goes on the compositor's stream and the event record + stream wait that ordered
+       it are not made (32 native channel threads, config 4: 26 100 -> 40 300 frames/s). The same holds for one channel
+       whose frames are cheaper on the GPU than those three calls are on its thread (config 4, one channel: 25 100 ->
+       28 000 frames/s), hence the work estimate. Reading the list in place from pinned memory was measured too:
+       config 3's launch 0.213 -> 0.226 ms, 32 channels 36 600 frames/s. */
+    const bool own_stream = dev->mixers.load() == 1 &&
+                            (double)format->width * format->height * (double)plan.ops.size() >= 32e6;
     if (ops_only + mask_bytes > 0) {
         if (ops_only)
             std::memcpy(t->h_ops, plan.ops.data(), ops_only);
         if (mask_bytes)
             std::memcpy((char*)t->h_ops + ops_only, plan.masks.data(), mask_bytes);
-        T_TRY(dev->event_get(cghip_device::EV_ORDER, &t->ev_ops));
-        T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, ops_only + mask_bytes, hipMemcpyHostToDevice, mixer->ops_stream));
-        T_HIP(hipEventRecord(t->ev_ops, mixer->ops_stream));
+        if (!own_stream) {
+            T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, ops_only + mask_bytes, hipMemcpyHostToDevice, t->stream));
+        } else {
+            T_TRY(dev->event_get(cghip_device::EV_ORDER, &t->ev_ops));
+            T_HIP(hipMemcpyAsync(t->d_ops, t->h_ops, ops_only + mask_bytes, hipMemcpyHostToDevice, mixer->ops_stream));
+            T_HIP(hipEventRecord(t->ev_ops, mixer->ops_stream));
+        }
     }
     const uint64_t* d_masks = (const uint64_t*)((const char*)t->d_ops + ops_only);
     /* the frame keeps its source planes alive and waits for their uploads (device.cpp:242-262 futures). A still or a
@@ -641,7 +654,8 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     }
     if (t->ev_ops)
         T_HIP(hipStreamWaitEvent(t->stream, t->ev_ops, 0));
-    T_HIP(hipEventRecord(t->ev_start, t->stream));
+    if (t->ev_start)
+        T_HIP(hipEventRecord(t->ev_start, t->stream));
     /* one launch per segment of the plan, in order on the mixer's stream; surfaces that are live across a cut travel
        through the frame buffer (RGBA0) and the ticket's spill buffers. An empty scene is one launch with zero ops
        that writes the all-zero frame (image_mixer.cpp:89-92). */
@@ -813,6 +827,12 @@ int cghip_ticket_kernel_ms(cghip_ticket* ticket, float* ms, int* launches)
     if (!ticket || !ms)
         return fail(CGHIP_ERR_INVALID, "bad arguments");
     CGHIP_TRY_HIP(hipEventSynchronize(ticket->ev_stop));
+    if (!ticket->ev_start) {
+        *ms = 0.0f;
+        if (launches)
+            *launches = ticket->launches;
+        return CGHIP_OK;
+    }
     CGHIP_TRY_HIP(hipEventElapsedTime(ms, ticket->ev_start, ticket->ev_stop));
     if (launches)
         *launches = ticket->launches;

@@ -327,6 +327,11 @@ struct pending_frame
     bool                                   readback;
 };
 
+int cghost_mixer_set_kernel_timing(void* h, int on)
+{
+    return guarded([&] { static_cast<host_mixer*>(h)->mixer->set_kernel_timing(on != 0); });
+}
+
 int cghost_mixer_render_async(void* h, const cghip_format* f, int readback, void** out)
 {
     return guarded([&] {

@@ -400,6 +400,7 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
     float                              last_ms_  = 0.0f;
     bool                               readback_ = true;
     bool                               field_rows_only_ = false;
+    bool                               kernel_timing_   = true;
 
     impl(const std::shared_ptr<device>& dev, int channel_id)
         : dev_(dev)
@@ -550,7 +551,8 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
         check(cghip_mixer_render_async(mixer_, &fmt, surfaces.data(), static_cast<int>(surfaces.size()), draws.data(),
                                        static_cast<int>(draws.size()),
                                        (readback_ ? CGHIP_RENDER_READBACK : 0u) |
-                                           (field_rows_only_ ? CGHIP_RENDER_FIELD_ROWS_ONLY : 0u),
+                                           (field_rows_only_ ? CGHIP_RENDER_FIELD_ROWS_ONLY : 0u) |
+                                           (kernel_timing_ ? 0u : CGHIP_RENDER_UNTIMED),
                                        &ticket),
               "cghip_mixer_render_async");
         /* consumers may hold the frame after the channel is gone (decklink / ndi queues): the buffer keeps its device */
@@ -652,6 +654,7 @@ void image_mixer::render_into(const core::video_format_desc& format_desc, void* 
 float image_mixer::last_kernel_ms() const { return impl_->last_ms_; }
 void  image_mixer::set_readback(bool on) { impl_->readback_ = on; }
 void  image_mixer::set_field_rows_only(bool on) { impl_->field_rows_only_ = on; }
+void  image_mixer::set_kernel_timing(bool on) { impl_->kernel_timing_ = on; }
 
 /* ------------------------------------------------------------------ accelerator */
 

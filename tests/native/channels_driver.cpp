@@ -4,7 +4,8 @@
  * drive their mixers in the reference (core/video_channel.cpp:125-193). bench.py drives channels from one Python
  * thread, which tops out near 25 000 submissions a second; this measures what the runtime itself sustains.
  *
- *   channels_driver <channels> <frames per channel> [width height]   ->  one JSON line
+ *   channels_driver <channels> <frames per channel> [width height [timed]]   ->  one JSON line
+ *   timed = 0: frames without the hipEvent pair that feeds a diagnostics graph (CGHIP_RENDER_UNTIMED)
  */
 #include <atomic>
 #include <chrono>
@@ -28,6 +29,7 @@ const char* cghost_last_error(void);
 int         cghost_device_count(void);
 int         cghost_mixer_create(int channel_id, int gpu_index, void** out);
 int         cghost_mixer_destroy(void* h);
+int         cghost_mixer_set_kernel_timing(void* h, int on);
 int         cghost_mixer_push(void* h, const cghip_transform* t);
 int         cghost_frame_create(void* h, int pixel_format, int nplanes, const cghost_plane* planes, const cghip_coord* coords,
                                 int ncoords, void** out);
@@ -64,6 +66,7 @@ int main(int argc, char** argv)
 {
     const int channels = argc > 1 ? std::atoi(argv[1]) : 32, frames = argc > 2 ? std::atoi(argv[2]) : 500;
     const int W = argc > 4 ? std::atoi(argv[3]) : 1920, H = argc > 4 ? std::atoi(argv[4]) : 1080;
+    const int timed = argc > 5 ? std::atoi(argv[5]) : 1;
     if (cghost_device_count() < 1) {
         std::fprintf(stderr, "no HIP device\n");
         return 2;
@@ -91,6 +94,7 @@ int main(int argc, char** argv)
         threads.emplace_back([&, c] {
             void* m = nullptr;
             CK(cghost_mixer_create(c + 1, 0, &m));
+            CK(cghost_mixer_set_kernel_timing(m, timed));
             void* fr[3];
             for (int k = 0; k < 3; ++k) {
                 cghost_plane p{W, H, 4, 8, src[k].data()};
@@ -149,10 +153,10 @@ int main(int argc, char** argv)
     for (auto& t : threads)
         t.join();
     const double s = std::chrono::duration<double>(t1 - t0).count();
-    std::printf("{\"workload\": \"config4 %dx%d\", \"channels\": %d, \"frames_per_channel\": %d, \"seconds\": %.4f, "
+    std::printf("{\"workload\": \"config4 %dx%d\", \"channels\": %d, \"kernel_timing\": %d, \"frames_per_channel\": %d, \"seconds\": %.4f, "
                 "\"frames_per_s\": %.1f, \"per_channel_fps\": %.1f, \"submit_us_per_frame\": %.1f, "
                 "\"wait_us_per_frame\": %.1f}\n",
-                W, H, channels, frames, s, channels * (double)frames / s, frames / s,
+                W, H, channels, timed, frames, s, channels * (double)frames / s, frames / s,
                 submit_ns / 1e3 / ((double)channels * frames), wait_ns / 1e3 / ((double)channels * frames));
     return 0;
 }

@@ -44,7 +44,7 @@ def _run_world_of_2(tmp_path, gpu):
     assert [x["rank"] for x in recs] == [0, 1] and all(x["world"] == 2 for x in recs)
     # every rank sees the same (max) time, and it is the slow rank's
     assert abs(recs[0]["max"] - recs[1]["max"]) < 1e-9 and recs[0]["max"] >= recs[1]["mine"] - 1e-9
-    assert recs[1]["mine"] > recs[0]["mine"]
+    assert abs(recs[0]["max"] - max(x["mine"] for x in recs)) < 1e-9
     # whole-job value = frames of all ranks / max time
     assert abs(recs[0]["value"] - 2 * 7 / recs[0]["max"]) < 1e-6
     # channel c lives on rank c % world (accelerator.cpp placement), every channel exactly once
