@@ -799,6 +799,10 @@ DEV Taps make_taps(int iu, int iv, int w, int h, uint32_t texel_bytes)
     x0           = iclamp(x0, 0, w - 1);
     y0           = iclamp(y0, 0, h - 1);
     const uint32_t r0 = (uint32_t)y0 * (uint32_t)w, r1 = (uint32_t)y1 * (uint32_t)w;
+#ifdef CGHIP_X_ONE_TAP /* measurement only (profiles/r02_tap_experiment.txt): all four taps read the first tap's texel */
+    const uint32_t o = (r0 + (uint32_t)x0) * texel_bytes;
+    return Taps{o, o + 0u * (uint32_t)x1, o + 0u * r1, o, iu & 0xff, iv & 0xff};
+#endif
     return Taps{(r0 + (uint32_t)x0) * texel_bytes, (r0 + (uint32_t)x1) * texel_bytes, (r1 + (uint32_t)x0) * texel_bytes,
                 (r1 + (uint32_t)x1) * texel_bytes, iu & 0xff, iv & 0xff};
 }
@@ -807,8 +811,12 @@ DEV Taps make_taps(int iu, int iv, int w, int h, uint32_t texel_bytes)
 DEV float tap1(uint64_t ptr, const Taps t)
 {
     const GB  b   = (GB)ptr;
+#ifdef CGHIP_X_ONE_LOAD /* measurement only: ONE load per plane, its value stands in for the other three taps */
+    const int a00 = load_at<uint8_t>(b, t.o00), a01 = a00 ^ (int)(t.o01 & 1u), a10 = a00 ^ (int)(t.o10 & 2u), a11 = a00 ^ (int)(t.o11 & 3u);
+#else
     const int a00 = load_at<uint8_t>(b, t.o00), a01 = load_at<uint8_t>(b, t.o01);
     const int a10 = load_at<uint8_t>(b, t.o10), a11 = load_at<uint8_t>(b, t.o11);
+#endif
     return (float)lerp8s(lerp8s(a00, a01, t.wx), lerp8s(a10, a11, t.wx), t.wy);
 }
 /* 4-channel plane: the four filtered bytes, memory order */
@@ -1685,10 +1693,239 @@ DEV void store_key4(const Fore& o, bool key1, float K0[4], float K1[4])
     });
 }
 
+/* ---- sampled sources in the 4-pixels-per-lane kernel ----
+ * FB_RECT8: an axis-aligned scaled rectangle (picture-in-picture boxes: image_kernel.cpp:195-205 with angle 0) of 8-bit
+ * ycbcr(a) planes or one packed 4-channel plane. KF_AXIS says that s depends on x alone and t on y alone (the other
+ * gradients are exactly zero), so everything that hangs on t - the two source rows, their clamps, the row weight - is
+ * the same for the whole wave and lives in scalar registers; a pixel computes its column taps and twelve (four) loads
+ * through scalar row bases. Same arithmetic as source_color + source_color_class<false>, term for term: fma(0, x, c)
+ * is c, and (v * size) * 256 equals v * (size * 256) because scaling by 2^8 commutes with rounding. */
+struct RowTaps { /* wave-uniform */
+    GB  r0, r1; /* row y0 and row y1 of the plane */
+    int wy;
+};
+DEV RowTaps row_taps(uint64_t ptr, int iv, int w, int h, uint32_t texel_bytes)
+{
+    int       y0 = iv >> 8;
+    const int y1 = iclamp(y0 + 1, 0, h - 1);
+    y0           = iclamp(y0, 0, h - 1);
+    const uint32_t pitch = (uint32_t)w * texel_bytes;
+    return RowTaps{(GB)ptr + (size_t)((uint32_t)y0 * pitch), (GB)ptr + (size_t)((uint32_t)y1 * pitch), iv & 0xff};
+}
+/* Per pixel: the two column taps are neighbours, so ONE load of two texels at column `x` serves both (planes are at
+ * least two texels wide, cghip_plan.cpp). CLAMP_TO_EDGE: left of the plane both taps are texel 0 - weight 0 on the pair
+ * (0, 1); right of column w - 2 both are texel w - 1 - weight 256 on the pair (w - 2, w - 1), and lerp8 with weight 256
+ * returns its second operand exactly. */
+struct ColTaps {
+    uint32_t x;
+    int      wx;
+};
+DEV ColTaps col_taps(int iu, int w)
+{
+    const int x0 = iu >> 8;
+    int       wx = iu & 0xff;
+    wx           = x0 < 0 ? 0 : wx;
+    wx           = x0 > w - 2 ? 256 : wx;
+    return ColTaps{(uint32_t)iclamp(x0, 0, w - 2), wx};
+}
+DEV float lerp_pairs8(uint32_t top, uint32_t bot, int wx, int wy) /* two 2-texel loads of a 1-channel plane */
+{
+    const int a = lerp8s((int)(top & 0xff), (int)(top >> 8), wx), b = lerp8s((int)(bot & 0xff), (int)(bot >> 8), wx);
+    return (float)lerp8s(a, b, wy);
+}
+template <bool PACKED, bool UNIT>
+DEV void fetch_rect8(const KOp& op, const HotG& g, int px0, int y, f4 col[4], uint32_t& cover)
+{
+    /* UNIT: a 1:1 source whose offset or width is off the 4-texel grid of the aligned bodies; plane 0 is addressed by
+       texel index, s and t stand for texel + 0.5 and the sizes for the plane's size relative to plane 0's
+       (source_color_class<true>: rint((p + .5) * ((size / size0) * 256)) - 128). Otherwise normalised coordinates from
+       the quad's affine map. */
+    const KTri& T  = op.tri[0];
+    auto coord = [](float v, float size256) -> int { return (int)__builtin_rintf(v * size256) - 128; };
+    /* t and what follows from it: computed by every lane, identical in all of them, moved to scalar registers */
+    const float  t   = UNIT ? (float)(y + g.unit_dy) + 0.5f : (float)__builtin_fma(T.a[1][2], (double)y, T.a[1][0]);
+    const float  sh0 = UNIT ? (g.fh0 / g.fh0) * 256.0f : g.fh0 * 256.0f, sh1 = UNIT ? (g.fh1 / g.fh0) * 256.0f : g.fh1 * 256.0f;
+    const float  sw0 = UNIT ? (g.fw0 / g.fw0) * 256.0f : g.fw0 * 256.0f, sw1 = UNIT ? (g.fw1 / g.fw0) * 256.0f : g.fw1 * 256.0f;
+    const int    iv0 = __builtin_amdgcn_readfirstlane(coord(t, sh0));
+    const double a01 = T.a[0][1], a00 = T.a[0][0];
+    const float  sc  = 1.0f / 255.0f;
+    float        s[4];
+    static_for<0, 4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int     x = px0 + i;
+        s[i]            = UNIT ? (float)(x + g.unit_dx) + 0.5f : (float)__builtin_fma(a01, (double)x, a00);
+        cover |= ((x >= g.x0) & (x < g.x1)) ? 1u << i : 0u;
+    });
+    if (PACKED) {
+        const RowTaps  r   = row_taps(g.ptr0, iv0, g.w0, g.h0, 4u);
+        const int      pf  = g.pixel_format;
+        const uint32_t sel = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
+        ColTaps        c[4];
+        u32x2          top[4], bot[4];
+        static_for<0, 4>([&](auto I) { c[decltype(I)::value] = col_taps(coord(s[decltype(I)::value], sw0), g.w0); });
+        static_for<0, 4>([&](auto I) { /* all loads first: one round trip per op */
+            constexpr int i = decltype(I)::value;
+            top[i] = load_at<u32x2>(r.r0, c[i].x * 4u), bot[i] = load_at<u32x2>(r.r1, c[i].x * 4u);
+        });
+        static_for<0, 4>([&](auto I) {
+            constexpr int  i  = decltype(I)::value;
+            const uint32_t wx = (uint32_t)c[i].wx;
+            const uint32_t m  = lerp8x4(lerp8x4(top[i].x, top[i].y, wx), lerp8x4(bot[i].x, bot[i].y, wx), (uint32_t)r.wy);
+            const uint32_t u  = __builtin_amdgcn_perm(m, m, sel);
+            col[i] = f4{(float)(u & 0xff) * sc, (float)((u >> 8) & 0xff) * sc, (float)((u >> 16) & 0xff) * sc, (float)(u >> 24) * sc};
+        });
+    } else {
+        const int     iv1 = __builtin_amdgcn_readfirstlane(coord(t, sh1));
+        const RowTaps ry = row_taps(g.ptr0, iv0, g.w0, g.h0, 1u);
+        const RowTaps rb = row_taps(g.ptr1, iv1, g.w1, g.h1, 1u), rr = row_taps(g.ptr2, iv1, g.w1, g.h1, 1u);
+        const bool    alpha = g.pixel_format == 6;
+        const bool    hd = g.flags & KF_IS_HD;
+        ColTaps       c0[4], c1[4];
+        uint32_t      yt[4], yb[4], bt[4], bb[4], rt[4], rbm[4], at[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            c0[i] = col_taps(coord(s[i], sw0), g.w0), c1[i] = col_taps(coord(s[i], sw1), g.w1);
+        });
+        static_for<0, 4>([&](auto I) { /* all loads first: one round trip per op */
+            constexpr int i = decltype(I)::value;
+            yt[i] = load_at<uint16_t>(ry.r0, c0[i].x), yb[i] = load_at<uint16_t>(ry.r1, c0[i].x);
+            bt[i] = load_at<uint16_t>(rb.r0, c1[i].x), bb[i] = load_at<uint16_t>(rb.r1, c1[i].x);
+            rt[i] = load_at<uint16_t>(rr.r0, c1[i].x), rbm[i] = load_at<uint16_t>(rr.r1, c1[i].x);
+        });
+        if (alpha) { /* wave-uniform */
+            const RowTaps ra = row_taps(g.ptr3, iv0, g.w0, g.h0, 1u);
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                at[i] = load_at<uint16_t>(ra.r0, c0[i].x), ab[i] = load_at<uint16_t>(ra.r1, c0[i].x);
+            });
+        }
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const float   Y = lerp_pairs8(yt[i], yb[i], c0[i].wx, ry.wy) * sc;
+            const float   Cb = lerp_pairs8(bt[i], bb[i], c1[i].wx, rb.wy) * sc, Cr = lerp_pairs8(rt[i], rbm[i], c1[i].wx, rb.wy) * sc;
+            const float   A = alpha ? lerp_pairs8(at[i], ab[i], c0[i].wx, ry.wy) * sc : 1.0f;
+            col[i] = ycbcra_to_rgba(Y, Cb, Cr, A, hd);
+        });
+    }
+}
+
+/* FB_RECT16: the same for 16-bit planes, filtered with fp32 weights like source_color_class16<false> (make_taps_f,
+ * bilerp_f), term for term. The two column taps again arrive in one load; at the plane's edges, where CLAMP_TO_EDGE
+ * makes both taps the same texel, the pair's other half is overwritten with it (a + w * (b - a) with b == a is a for any
+ * w; a weight of 1 would not give b exactly). */
+struct RowTapsF { /* wave-uniform */
+    GB    r0, r1;
+    float wy;
+};
+DEV RowTapsF row_taps_f(uint64_t ptr, float v, int w, int h, uint32_t texel_bytes)
+{
+    const float fy = __builtin_floorf(v);
+    int         y0 = (int)fy;
+    const int   y1 = iclamp(y0 + 1, 0, h - 1);
+    y0             = iclamp(y0, 0, h - 1);
+    const uint32_t pitch = (uint32_t)w * texel_bytes;
+    return RowTapsF{(GB)ptr + (size_t)((uint32_t)y0 * pitch), (GB)ptr + (size_t)((uint32_t)y1 * pitch), v - fy};
+}
+struct ColTapsF {
+    uint32_t x;    /* column of the pair */
+    int      edge; /* -1: both taps are the pair's first texel, +1: both are its second, 0: the pair as loaded */
+    uint32_t sel;  /* the same as a byte selector for a pair of 16-bit texels in one dword */
+    float    wx;
+};
+DEV ColTapsF col_taps_f(float u, int w)
+{
+    const float fx = __builtin_floorf(u);
+    const int   x0 = (int)fx;
+    const bool  first = x0 < 0, second = x0 > w - 2;
+    return ColTapsF{(uint32_t)iclamp(x0, 0, w - 2), first ? -1 : (second ? 1 : 0),
+                    first ? 0x01000100u : (second ? 0x03020302u : 0x03020100u), u - fx};
+}
+DEV float lerp_pairs16(uint32_t top, uint32_t bot, const ColTapsF c, float wy)
+{
+    const float    sc = 1.0f / 65535.0f;
+    const uint32_t t = __builtin_amdgcn_perm(top, top, c.sel), b = __builtin_amdgcn_perm(bot, bot, c.sel);
+    return bilerp_f((float)(t & 0xffff) * sc, (float)(t >> 16) * sc, (float)(b & 0xffff) * sc, (float)(b >> 16) * sc, c.wx, wy);
+}
+template <bool PACKED, bool UNIT>
+DEV void fetch_rect16(const KOp& op, const HotG& g, int px0, int y, f4 col[4], uint32_t& cover)
+{
+    const KTri& T = op.tri[0];
+    auto coord = [](float v, float size) -> float { return v * size - 0.5f; };
+    const float  t   = UNIT ? (float)(y + g.unit_dy) + 0.5f : (float)__builtin_fma(T.a[1][2], (double)y, T.a[1][0]);
+    const float  sh0 = UNIT ? g.fh0 / g.fh0 : g.fh0, sh1 = UNIT ? g.fh1 / g.fh0 : g.fh1;
+    const float  sw0 = UNIT ? g.fw0 / g.fw0 : g.fw0, sw1 = UNIT ? g.fw1 / g.fw0 : g.fw1;
+    const float  v0  = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, coord(t, sh0))));
+    const double a01 = T.a[0][1], a00 = T.a[0][0];
+    float        s[4];
+    static_for<0, 4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int     x = px0 + i;
+        s[i]            = UNIT ? (float)(x + g.unit_dx) + 0.5f : (float)__builtin_fma(a01, (double)x, a00);
+        cover |= ((x >= g.x0) & (x < g.x1)) ? 1u << i : 0u;
+    });
+    if (PACKED) {
+        const RowTapsF r = row_taps_f(g.ptr0, v0, g.w0, g.h0, 8u);
+        ColTapsF       c[4];
+        u32x4          top[4], bot[4];
+        static_for<0, 4>([&](auto I) { c[decltype(I)::value] = col_taps_f(coord(s[decltype(I)::value], sw0), g.w0); });
+        static_for<0, 4>([&](auto I) { /* all loads first */
+            constexpr int i = decltype(I)::value;
+            top[i] = load_at<u32x4>(r.r0, c[i].x * 8u), bot[i] = load_at<u32x4>(r.r1, c[i].x * 8u);
+        });
+        const float sc = 1.0f / 65535.0f;
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const bool    first = c[i].edge < 0, second = c[i].edge > 0;
+            const u32x2   a00v = {second ? top[i].z : top[i].x, second ? top[i].w : top[i].y};
+            const u32x2   a01v = {first ? top[i].x : top[i].z, first ? top[i].y : top[i].w};
+            const u32x2   a10v = {second ? bot[i].z : bot[i].x, second ? bot[i].w : bot[i].y};
+            const u32x2   a11v = {first ? bot[i].x : bot[i].z, first ? bot[i].y : bot[i].w};
+#define CH(v, k) ((float)((k) == 0 ? (v).x & 0xffff : (k) == 1 ? (v).x >> 16 : (k) == 2 ? (v).y & 0xffff : (v).y >> 16) * sc)
+#define LERP(k) bilerp_f(CH(a00v, k), CH(a01v, k), CH(a10v, k), CH(a11v, k), c[i].wx, r.wy)
+            const float m0 = LERP(0), m1 = LERP(1), m2 = LERP(2), m3 = LERP(3);
+#undef LERP
+#undef CH
+            col[i] = swizzle_format(g.pixel_format, f4{m2, m1, m0, m3});
+        });
+    } else {
+        const float    v1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, coord(t, sh1))));
+        const RowTapsF ry = row_taps_f(g.ptr0, v0, g.w0, g.h0, 2u);
+        const RowTapsF rb = row_taps_f(g.ptr1, v1, g.w1, g.h1, 2u), rr = row_taps_f(g.ptr2, v1, g.w1, g.h1, 2u);
+        const bool     alpha = g.pixel_format == 6;
+        const bool     hd = g.flags & KF_IS_HD;
+        ColTapsF       c0[4], c1[4];
+        uint32_t       yt[4], yb[4], bt[4], bb[4], rt[4], rbm[4], at[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            c0[i] = col_taps_f(coord(s[i], sw0), g.w0), c1[i] = col_taps_f(coord(s[i], sw1), g.w1);
+        });
+        static_for<0, 4>([&](auto I) { /* all loads first */
+            constexpr int i = decltype(I)::value;
+            yt[i] = load_at<uint32_t>(ry.r0, c0[i].x * 2u), yb[i] = load_at<uint32_t>(ry.r1, c0[i].x * 2u);
+            bt[i] = load_at<uint32_t>(rb.r0, c1[i].x * 2u), bb[i] = load_at<uint32_t>(rb.r1, c1[i].x * 2u);
+            rt[i] = load_at<uint32_t>(rr.r0, c1[i].x * 2u), rbm[i] = load_at<uint32_t>(rr.r1, c1[i].x * 2u);
+        });
+        if (alpha) { /* wave-uniform */
+            const RowTapsF ra = row_taps_f(g.ptr3, v0, g.w0, g.h0, 2u);
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                at[i] = load_at<uint32_t>(ra.r0, c0[i].x * 2u), ab[i] = load_at<uint32_t>(ra.r1, c0[i].x * 2u);
+            });
+        }
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const float   Y = lerp_pairs16(yt[i], yb[i], c0[i], ry.wy);
+            const float   Cb = lerp_pairs16(bt[i], bb[i], c1[i], rb.wy), Cr = lerp_pairs16(rt[i], rbm[i], c1[i], rb.wy);
+            const float   A = alpha ? lerp_pairs16(at[i], ab[i], c0[i], ry.wy) : 1.0f;
+            col[i] = ycbcra_to_rgba(Y, Cb, Cr, A, hd);
+        });
+    }
+}
+
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
-template <int BITS, bool FULL>
+template <int BITS, bool FULL, bool SAMPLED>
 DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, const KSpill& sp)
 {
     constexpr int P    = 4;
@@ -1757,6 +1994,9 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
         const int  sx = px0 + h.unit_dx;
         const bool red_only = h.flags & KF_RED_ONLY;
         f4         col[P];
+        uint32_t   cover = 0; /* sampled bodies: which of the lane's pixels the quad covers */
+        if constexpr (!SAMPLED) /* the sampled bodies are empty in this instantiation (never planned for it) */
+            static_for<0, P>([&](auto I) { col[decltype(I)::value] = f4{0, 0, 0, 0}; });
 #define SY opaque_s(y + h.unit_dy)
 #define PLANAR16(HX, HY)                                                                                               \
     if constexpr (BITS == 16)                                                                                          \
@@ -1771,6 +2011,38 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 } else {
                     static_for<0, P>([&](auto I) { col[decltype(I)::value] = f4{0, 0, 0, 0}; }); /* never planned */
                 }
+                break;
+            case FB_RECT8 + 0:
+                if constexpr (SAMPLED)
+                    fetch_rect8<false, false>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT8 + 1:
+                if constexpr (SAMPLED)
+                    fetch_rect8<true, false>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT8 + 2:
+                if constexpr (SAMPLED)
+                    fetch_rect8<false, true>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT8 + 3:
+                if constexpr (SAMPLED)
+                    fetch_rect8<true, true>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT16 + 0:
+                if constexpr (SAMPLED)
+                    fetch_rect16<false, false>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT16 + 1:
+                if constexpr (SAMPLED)
+                    fetch_rect16<true, false>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT16 + 2:
+                if constexpr (SAMPLED)
+                    fetch_rect16<false, true>(op, load_hot_g(op), px0, y, col, cover);
+                break;
+            case FB_RECT16 + 3:
+                if constexpr (SAMPLED)
+                    fetch_rect16<true, true>(op, load_hot_g(op), px0, y, col, cover);
                 break;
             case FB_PACKED8: fetch_packed<8>(h, sx, SY, col); break;
             case FB_PACKED16: fetch_packed<16>(h, sx, SY, col); break;
@@ -1806,6 +2078,12 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
             static_for<0, P>([&](auto I) {
                 constexpr int i = decltype(I)::value;
                 col[i] = sel4((uint32_t)(px0 + i - h.x0) < span, col[i], f4{0, 0, 0, 0});
+            });
+        }
+        if (SAMPLED && h.fetch_body >= FB_RECT8) { /* after the adjustments, which turn zero into something else */
+            static_for<0, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                col[i] = sel4((cover >> i) & 1u, col[i], f4{0, 0, 0, 0});
             });
         }
         if constexpr (!FULL) {
@@ -1916,13 +2194,31 @@ template <int BITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEAN_WAVES))) void cghip_composite_fast(
     const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
 {
-    composite_fast_body<BITS, false>(ops, nops, out, W, H, field_mode, sp);
+    composite_fast_body<BITS, false, false>(ops, nops, out, W, H, field_mode, sp);
 }
 template <int BITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void cghip_composite_fast_full(
     const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
 {
-    composite_fast_body<BITS, true>(ops, nops, out, W, H, field_mode, sp);
+    composite_fast_body<BITS, true, false>(ops, nops, out, W, H, field_mode, sp);
+}
+/* The same two with the sampled fetch bodies (FB_RECT8) compiled in, for launches that hold such a draw.
+ * Kernels of their own: with those bodies in it the kernel of full-screen stacks allocated its registers differently
+ * and the headline frame went from 0.207 to 0.284 ms. */
+#ifndef SAMPLED_WAVES
+#define SAMPLED_WAVES 5
+#endif
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SAMPLED_WAVES))) void cghip_composite_fast_s(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, false, true>(ops, nops, out, W, H, field_mode, sp);
+}
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void cghip_composite_fast_full_s(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, true, true>(ops, nops, out, W, H, field_mode, sp);
 }
 
 #if CGHIP_FRAME_BITS == 8
@@ -2018,10 +2314,15 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
         block = dim3(64 * rows);
         const unsigned nbx = (unsigned)((gw + 255) / 256), nby = (unsigned)((gh + rows - 1) / rows);
         const dim3     grid = tiles(nbx, nby, nbx * nby >= XCD_MIN_TILES && !cghip_g_plain_tiles);
-        if (!full)
+        const bool sampled = fast == 2; /* the launch holds a draw with a sampled fetch body */
+        if (!full && !sampled)
             hipLaunchKernelGGL((cghip_composite_fast<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
-        else
+        else if (!sampled)
             hipLaunchKernelGGL((cghip_composite_fast_full<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+        else if (!full)
+            hipLaunchKernelGGL((cghip_composite_fast_s<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+        else
+            hipLaunchKernelGGL((cghip_composite_fast_full_s<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         return hipGetLastError();
     }
     const dim3 grid = tiles((unsigned)((gw + 63) / 64), (unsigned)((gh + 3) / 4), false);

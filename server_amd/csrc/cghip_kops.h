@@ -32,6 +32,7 @@ enum KOpFlags : uint32_t {
     KF_ADDITIVE    = 1u << 9, /* keyer::additive */
     KF_EDGE        = 1u << 11, /* fast kernel: x0 or x1 is not a multiple of 4, lanes on the box edge mask their pixels */
     KF_SOLID       = 1u << 10, /* KF_RECT and the source is one 1x1 packed texel (colour producer): every sample is it */
+    KF_AXIS        = 1u << 13, /* KF_RECT, not projective, and s depends on x alone, t on y alone (exact zeros) */
     KF_RED_ONLY    = 1u << 12  /* fast kernel: planar draw into a key surface without colour adjustments: only red and
                                   alpha are looked at (image_mixer.cpp:174-183), the Cb plane is not read */
 };
@@ -40,7 +41,9 @@ enum KFastClass : int32_t {
     FC_NONE   = 0,
     FC_PACKED = 1, /* one 4-channel plane (bgra / rgba / argb / abgr), unit scale */
     FC_PLANAR = 2, /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
-    FC_SURFACE = 3 /* KOP_DRAW_SURFACE: a layer / mix temporary composited 1:1 (any blend mode, either keyer) */
+    FC_SURFACE = 3, /* KOP_DRAW_SURFACE: a layer / mix temporary composited 1:1 (any blend mode, either keyer) */
+    FC_SAMPLED = 4  /* planes in one of the straight-line sampling layouts (KSampleClass), axis-aligned box at
+                       any scale or 1:1 off the 4-texel grid: four bilinear fetches per lane, coverage per pixel */
 };
 
 /* Which straight-line bodies of the 4-pixels-per-lane kernel run a draw (host: classify_fast). The kernel switches on
@@ -50,7 +53,10 @@ enum KFetchBody : int32_t {
     FB_PACKED8  = 1,
     FB_PACKED16 = 2,
     FB_PLANAR8  = 3, /* + csx + 2 * csy */
-    FB_PLANAR16 = 7  /* + csx + 2 * csy */
+    FB_PLANAR16 = 7, /* + csx + 2 * csy */
+    FB_RECT16   = 16, /* the same four for 16-bit planes (fp32 filter weights) */
+    FB_RECT8    = 12  /* FC_SAMPLED with KF_AXIS or KF_UNIT_SCALE and 8-bit planes: + 0 ycbcr(a) planes, + 1 one packed
+                         plane, + 2 if KF_UNIT_SCALE (a 1:1 source off the aligned bodies' 4-texel grid) */
 };
 enum KBlendBody : int32_t {
     BB_RGBA_SIMPLE  = 0, /* no key, no invert, linear keyer */

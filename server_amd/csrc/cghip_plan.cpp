@@ -188,15 +188,33 @@ int floor_div256(int64_t v) { return (int)((v >= 0) ? v / 256 : -((-v + 255) / 2
 /* Which draws the 4-pixels-per-lane kernel (cghip_composite_fast) can run: unit-scale sources whose texels
  * can be fetched with aligned vector loads, normal blend into the frame or a key surface. */
 static void classify_fast_draw(KOp& op, int frame_w);
+static int  g_no_sampled_fast = 0; /* test hook: sampled draws stay with the general kernel */
 static void classify_fast(KOp& op, int frame_w)
 {
     classify_fast_draw(op, frame_w);
+    /* Axis-aligned boxes at any scale (picture-in-picture) and 1:1 sources off the 4-texel grid of the aligned bodies,
+       from planes the general kernel has a straight-line sampling body for (classify_sampling, called before):
+       the lane fetches four bilinear samples - source rows and row weight are wave-uniform - and zeroes the pixels the
+       box does not cover, which leaves the target as it is unless the draw inverts. Rotated and perspective quads stay
+       with the 1-pixel-per-lane kernel: its per-pixel colour inlined four times was measured at 10.9 (rotated) and 7.1
+       (perspective) ps per pixel against 6.3 and 5.4 there (tests/gpu_probe.py, 16 layers 2160p). */
+    if (op.fast_class == FC_NONE && op.kind == KOP_DRAW_PLANES && op.blend_mode == 0 && !(op.flags & KF_INVERT) &&
+        !g_no_sampled_fast && ((op.flags & KF_AXIS) || (op.flags & KF_UNIT_SCALE)) &&
+        op.sample_class != SC_GENERIC) {
+        bool wide_enough = true; /* the body fetches both column taps with one two-texel load */
+        for (int n = 0; n < op.nplanes; ++n)
+            wide_enough = wide_enough && op.planes[n].w >= 2;
+        if (wide_enough)
+            op.fast_class = FC_SAMPLED;
+    }
     if (op.fast_class == FC_NONE)
         return;
     /* the bodies of cghip_composite_fast that run this draw */
     const bool wide = op.planes[0].bits == 16;
-    op.fetch_body   = op.fast_class == FC_SURFACE  ? (int)FB_SURFACE
-                      : op.fast_class == FC_PACKED ? (wide ? (int)FB_PACKED16 : (int)FB_PACKED8)
+    op.fetch_body   = op.fast_class == FC_SURFACE   ? (int)FB_SURFACE
+                      : op.fast_class == FC_SAMPLED ? (wide ? (int)FB_RECT16 : (int)FB_RECT8) + (op.sample_class == SC_PACKED8 || op.sample_class == SC_PACKED16 ? 1 : 0) +
+                                            ((op.flags & KF_UNIT_SCALE) ? 2 : 0)
+                      : op.fast_class == FC_PACKED  ? (wide ? (int)FB_PACKED16 : (int)FB_PACKED8)
                                                    : (wide ? (int)FB_PLANAR16 : (int)FB_PLANAR8) + op.csx + 2 * op.csy;
     const bool to_key = op.dst >= KS_KEY0;
     if (to_key && op.fast_class == FC_PLANAR && !(op.flags & (KF_CHROMA | KF_LEVELS | KF_CSB)))
@@ -470,6 +488,9 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
         projective = projective || (float)q[i].q != 1.0f;
     if (projective)
         op.flags |= KF_PROJECTIVE;
+    /* s hangs on x alone and t on y alone: the fetch body for picture-in-picture boxes keeps t's side in scalars */
+    if (rect && !projective && op.tri[0].a[0][2] == 0.0 && op.tri[0].a[1][1] == 0.0)
+        op.flags |= KF_AXIS;
 
     int bx0, by0, bx1, by1;
     if (rect) {
@@ -607,11 +628,28 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
     /* 1. kernel class per op: min-cost path, states 0 = general, 1 = fast. Costs in picoseconds, measured with
        tests/gpu_segments_probe.py and tests/gpu_probe.py: per pixel of a draw's box a layer
        takes about 4.8 ps in the general kernel and 1.6 (16-bit) / 1.9 (8-bit) ps in the fast one; a cut costs a round
-       trip of the frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (about 6 us with the extra launch's ramp). */
+       trip of the frame through HBM (3.1 / 1.6 ps per frame pixel) plus the gap between two launches (see `gap` below). */
     std::vector<uint8_t> cls((size_t)n, out->fast && !g_force_general ? 1 : 0);
     if (n > 0 && !out->fast && !g_force_general && g_max_segments > 1) {
-        const double per_px[2] = {4.8, fmt.bits == 16 ? 1.6 : 1.9};
-        const double rt_px = fmt.bits == 16 ? 3.1 : 1.6, gap = 6e6;
+        /* tests/gpu_probe.py, 16 layers 2160p 8-bit, ps per pixel of the draw's box. General kernel: axis-aligned 4.6 -
+           4.9, perspective 5.4, rotated 6.3, composite of a temporary with a blend mode 4.4. Fast kernel: aligned 1:1
+           1.9 (16-bit 1.6), sampled box of planes 3.5 (5.0 into a temporary, where the kernel holds 128 registers),
+           of a packed plane 2.6 (16-bit planes: 4.7 and 3.7), composite of a temporary 3.3. */
+        /* gap: what a cut costs beyond the bytes. Two launches back to back are 6 us apart, but the general kernel's time
+           is not proportional to its draws' pixels (every wave pays set-up, surface loads and stores): BASELINE config 2
+           cut in two - the first three layers to the fast kernel, predicted gain 7 us - ran 0.102 ms against 0.086 ms in
+           one general launch. 15 us keeps such marginal cuts away and every cut the tests and probes show to pay. */
+        const double rt_px = fmt.bits == 16 ? 3.1 : 1.6, gap = 15e6;
+        auto per_px = [&](const KOp& o, int k) -> double {
+            const bool planes = o.kind == KOP_DRAW_PLANES, temp = o.dst == KS_RGBA1 || o.dst == KS_RGBA2;
+            if (k == 0)
+                return o.kind == KOP_DRAW_SURFACE ? 4.4 : (planes && !(o.flags & KF_RECT)) ? 6.0 : 4.8;
+            if (planes && o.fetch_body >= FB_RECT8)
+                return ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.35 : 1.0) + (temp ? 1.5 : 0.0);
+            if (o.kind == KOP_DRAW_SURFACE)
+                return o.blend_mode != 0 ? 3.3 : 1.9;
+            return fmt.bits == 16 ? 1.6 : 1.9;
+        };
         /* into the fast kernel the whole frame makes the trip; into the general one, which may cover only the box of
            its draws, this draw's box stands in for that */
         auto cut_into = [&](int k, double area) { return (gap + rt_px * (k == 1 ? (double)W * H : area)) * g_cut_scale; };
@@ -634,7 +672,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
                 if (k == 1 && !clr && o.fast_class == FC_NONE)
                     continue;
                 for (int j = 0; j < 2; ++j) {
-                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut_into(k, open_area) : 0.0) + area * per_px[k];
+                    const double c = cost[(size_t)i * 2 + j] + (j != k ? cut_into(k, open_area) : 0.0) + area * per_px(o, k);
                     if (c < cost[(size_t)(i + 1) * 2 + k]) {
                         cost[(size_t)(i + 1) * 2 + k] = c;
                         from[(size_t)(i + 1) * 2 + k] = (uint8_t)j;
@@ -686,10 +724,17 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             else
                 zero &= ~surf_bit(o.dst);
         }
-        for (int i = sg.first + sg.count; i < n; ++i)
-            if (ops[(size_t)i].kind != KOP_CLEAR)
-                later |= refs_of(ops[(size_t)i]);
+        uint32_t reset = 0; /* surfaces a later launch clears before anything looks at them: dead at this cut */
+        for (int i = sg.first + sg.count; i < n; ++i) {
+            if (ops[(size_t)i].kind == KOP_CLEAR)
+                reset |= surf_bit(ops[(size_t)i].dst) & ~later;
+            else
+                later |= refs_of(ops[(size_t)i]) & ~reset;
+        }
         sg.full       = (touched & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0;
+        sg.sampled    = false;
+        for (int i = sg.first; i < sg.first + sg.count && sg.fast; ++i)
+            sg.sampled = sg.sampled || (ops[(size_t)i].kind == KOP_DRAW_PLANES && ops[(size_t)i].fetch_body >= FB_RECT8);
         sg.load_mask  = touched & in_mem;
         sg.store_mask = written & ~zero & later;
         if (si == 0)
@@ -878,8 +923,8 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
                 continue;
         }
         drawn[op.dst].add(op.x0, op.y0, op.x1, op.y1);
-        classify_fast(op, fmt->width); /* dst is known now */
         classify_sampling(op);
+        classify_fast(op, fmt->width); /* dst is known now */
         out->ops.push_back(op);
         if (d.source_surface < 0)
             for (int n = 0; n < d.nplanes; ++n)
@@ -922,6 +967,8 @@ extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }
 /* test hooks: one launch of the general kernel per frame / at most n launches per frame (1 = never cut) */
 extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_general = on; }
 extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling = on; }
+/* sampled (scaled / rotated / perspective) draws stay with the 1-pixel-per-lane kernel, as before FC_SAMPLED existed */
+extern "C" void cghip_debug_no_sampled_fast(int on) { cghip::g_no_sampled_fast = on; }
 extern "C" void cghip_debug_keep_hidden_ops(int on) { cghip::g_keep_hidden_ops = on; }
 extern "C" void cghip_debug_full_frame_composites(int on) { cghip::g_full_frame_composites = on; }
 extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }

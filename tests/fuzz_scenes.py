@@ -171,3 +171,60 @@ def fuzz_fast_scene(seed, bits=8, full=False):
             continue
         ops.append(S.layer(src, **t))
     return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))
+
+
+def fuzz_box_scene(seed, bits=8, full=False):
+    """Random stacks with picture-in-picture boxes: axis-aligned layers at any scale and offset (sources of their own
+    size, odd widths and tiny planes included) and 1:1 layers moved by whole pixels off the 4-pixel grid, between
+    ordinary unit-scale layers. All of it is the 4-pixels-per-lane kernel's class since it samples boxes itself
+    (cghip_kernels.hip: fetch_rect8 / fetch_rect16); full=True puts some of the boxes into blend-mode layers."""
+    rng = random.Random(9000011 * seed + bits)
+    W, H = rng.choice([(96, 64), (128, 36), (260, 50), (64, 90), (200, 40)])
+    ops = []
+    s = 12000 + 137 * seed
+    for i in range(rng.randint(2, 6)):
+        f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420"])
+        mode = rng.choice(["box", "box", "box", "shift", "plain"])
+        if mode == "box":  # a source of its own size; 4:2:x needs even sizes, chroma planes stay >= 2 texels wide
+            sw, sh = rng.choice([(W, H), (W // 2, H // 2), (2 * W, 2 * H), (40, 30), (6, 4), (4, 2), (130, 70)])
+        else:
+            sw, sh = W, H
+        kind = rng.choice(["smooth", "noise", "video"])
+        if f in ("bgra", "rgba", "argb", "abgr"):
+            if mode == "box" and rng.random() < 0.3:
+                sw, sh = rng.choice([(2, 2), (3, 5), (37, 21)])  # packed planes may be odd and tiny
+            src = S.frame(f, [(sw, sh, 4, rng.choice(["premul", "noise", "smooth"]), s + i)], bits)
+        else:
+            src = S.ycbcr(sw, sh, f[-3:], kind, s + i, bits=bits, alpha=f.startswith("ycbcra"))
+        t = {}
+        r = rng.random
+        if mode == "box":
+            sx, sy = round(rng.uniform(0.15, 1.4), 3), round(rng.uniform(0.15, 1.4), 3)
+            t.update(fill_scale=[sx, sy], fill_translation=[round(rng.uniform(-0.3, 0.9), 3), round(rng.uniform(-0.3, 0.9), 3)])
+            if r() < 0.3:
+                t["crop_ul"], t["crop_lr"] = [round(rng.uniform(0, 0.3), 2), round(rng.uniform(0, 0.3), 2)], \
+                                             [round(rng.uniform(0.6, 1.0), 2), round(rng.uniform(0.6, 1.0), 2)]
+        elif mode == "shift":  # whole pixels, mostly not multiples of 4
+            t["fill_translation"] = [rng.randint(-9, 9) / W, rng.randint(-5, 5) / H]
+        if r() < 0.7:
+            t["opacity"] = rng.choice([1.0, 0.5, 0.25, round(r(), 3), 0.73])
+        if r() < 0.2:
+            x0, x1 = sorted(rng.sample(range(0, W + 1), 2))
+            y0, y1 = sorted(rng.sample(range(0, H + 1), 2))
+            if x1 > x0 and y1 > y0:
+                t["clip_translation"], t["clip_scale"] = [x0 / W, y0 / H], [(x1 - x0) / W, (y1 - y0) / H]
+        if r() < 0.2:
+            t.update(levels_min_input=round(rng.uniform(0, 0.2), 3), levels_max_input=round(rng.uniform(0.7, 1.0), 3),
+                     levels_gamma=rng.choice([1.0, 1.0, 0.6, 1.2]), levels_min_output=rng.choice([0.0, 0.1]),
+                     levels_max_output=rng.choice([1.0, 0.9]))
+        if r() < 0.15:
+            t.update(brightness=round(rng.uniform(0.6, 1.4), 2), saturation=round(rng.uniform(0.0, 1.6), 2),
+                     contrast=round(rng.uniform(0.6, 1.4), 2))
+        if r() < 0.15:
+            t.update(dict(S.CHROMA, chroma_target_hue=rng.choice([120.0, 240.0, 30.0])))
+        if r() < 0.2:
+            t["is_key"] = 1
+        elif full and r() < 0.4:
+            t["blend_mode"] = rng.choice(S.BLEND_NAMES)
+        ops.append(S.layer(src, **t))
+    return S.scene("fuzzbox_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 0, 1, 2]))

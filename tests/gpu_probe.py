@@ -18,7 +18,10 @@ def stack(kind, bits):
          "g_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]), "g_rot": dict(opacity=0.8, angle=0.05),
          "g_pers": dict(opacity=0.8, pers_ul=[0.02, 0.01], pers_lr=[0.98, 0.99]),
          "g_blend": dict(opacity=0.8, blend_mode=os.environ.get("PROBE_BLEND", "screen")), "g_bgra_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
-         "g_unit": dict(opacity=0.8, fill_translation=[1.0 / W, 0.0])}[kind]
+         "g_unit": dict(opacity=0.8, fill_translation=[1.0 / W, 0.0]),
+         # the same inside blend-mode layers: the kernels that also hold the two RGBA temporaries
+         "g_rect_blend": dict(opacity=0.8, fill_scale=[0.97, 0.97], blend_mode=os.environ.get("PROBE_BLEND", "screen")),
+         "g_rot_blend": dict(opacity=0.8, angle=0.05, blend_mode=os.environ.get("PROBE_BLEND", "screen"))}[kind]
     ops = []
     for i in range(NL):
         spec = S.bgra(W, H, "premul", 500 + i, bits=bits) if "bgra" in kind else S.ycbcr(W, H, SUB, "video", 500 + i, bits=bits)

@@ -33,8 +33,9 @@ class KOp(C.Structure):
 
 
 KOP_CLEAR, KOP_DRAW_PLANES, KOP_DRAW_SURFACE = 0, 1, 2
-KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE, KF_SOLID, KF_EDGE = \
-    [1 << i for i in range(12)]
+(KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE,
+ KF_SOLID, KF_EDGE, KF_RED_ONLY, KF_AXIS) = [1 << i for i in range(14)]
+FC_NONE, FC_PACKED, FC_PLANAR, FC_SURFACE, FC_SAMPLED = range(5)
 KS_RGBA0, KS_RGBA1, KS_RGBA2, KS_KEY0, KS_KEY1 = range(5)
 
 
@@ -75,9 +76,13 @@ def plan_segments(fmt, surfaces, draws):
     return [dict(zip(SEG_FIELDS, out[i * 10:(i + 1) * 10])) for i in range(n)]
 
 
-def set_cut_policy(cut_cost_scale=1.0, max_segments=8):
+def set_cut_policy(cut_cost_scale=1.0, max_segments=8, sampled_fast=True):
+    """sampled_fast=False: scaled / rotated / perspective draws stay with the 1-pixel-per-lane kernel (as they did
+    before the 4-pixels-per-lane kernel learned to sample), so that scenes mixing them with unit-scale layers still
+    exercise the cutting of a frame into launches; today only exotic pixel formats and inverted partial quads do."""
     import server_amd as A
     L = A.lib()
+    L.cghip_debug_no_sampled_fast(0 if sampled_fast else 1)
     L.cghip_debug_cut_cost_scale.argtypes = [C.c_double]
     L.cghip_debug_cut_cost_scale.restype = None
     L.cghip_debug_cut_cost_scale(float(cut_cost_scale))

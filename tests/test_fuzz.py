@@ -191,6 +191,54 @@ def test_fast_kernel_on_random_unit_scale_stacks(bits, full):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("full", [False, True], ids=["normal_blend", "with_temporaries"])
+@pytest.mark.parametrize("bits", [8, 16])
+def test_fast_kernel_samples_boxes_like_the_general_kernel(bits, full):
+    """Picture-in-picture boxes (axis-aligned, any scale, sources of their own size down to 2 texels) and 1:1 layers off
+    the 4-pixel grid run in the 4-pixels-per-lane kernel (fetch_rect8 / fetch_rect16: wave-uniform rows, one two-texel
+    load per tap pair). Same arithmetic as the general kernel's sampling bodies: bit for bit equal to it in 8-bit
+    frames - 16-bit planes in them included -, and to the oracle."""
+    import server_amd as A
+    from fuzz_scenes import fuzz_box_scene
+    m = A.Mixer(channel_id=7, gpu=0)
+    L = A.lib()
+    one_launch = 0
+    try:
+        for seed in range(300):
+            sc = fuzz_box_scene(seed, bits, full)
+            cache = {}
+            before = m.device_info()["kernel_launches"]
+            fast = S.run_product(sc, mixer=m, planes_cache=cache)
+            one_launch += m.device_info()["kernel_launches"] - before == 1
+            L.cghip_debug_force_general_kernel(1)
+            try:
+                general = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_force_general_kernel(0)
+            sd = S.diff_stats(fast, general)
+            assert sd["max"] == 0 if bits == 8 else (sd["gt2"] <= 1e-3 and sd["gt0"] <= 2e-2), (seed, sd)
+            ref = S.run_oracle(sc, "cpu", cache)
+            st = S.diff_stats(fast, ref)
+            if bits == 8:
+                pow_used = any(o[0] == "push" and o[1].get("levels_gamma", 1.0) != 1.0 for o in sc["ops"])
+                assert (st["max"] <= 1 and st["gt0"] <= 1e-4) if pow_used else st["max"] == 0, (seed, st)
+            else:
+                # +-2 LSB16 outside the scene's amplifying pixels, at all but 2e-4 of a scene's pixels: boxes inside
+                # blend-mode layers divide by the box edge's small alpha (shader.frag:427-428), and the probes find
+                # most but not every such pixel (measured worst: tests/golden/parity16_report.json)
+                st = P16.check(sc, fast, ref, cache, unexplained_fraction=2e-4)
+                assert st["gt2"] <= 0.15 and st["max_outside_amplifying"] <= 32, (seed, st)
+                key = "fuzz_box_300_scenes_16bit" + ("_with_temporaries" if full else "")
+                w = P16.REPORT.setdefault(key, {"max": 0, "gt2": 0.0, "max_outside_amplifying": 0, "scenes_beyond_2": 0})
+                w["max"], w["gt2"] = max(w["max"], st["max"]), max(w["gt2"], st["gt2"])
+                w["max_outside_amplifying"] = max(w["max_outside_amplifying"], st["max_outside_amplifying"])
+                w["scenes_beyond_2"] += st["pixels_gt2"] > 0
+    finally:
+        m.close()
+    assert one_launch == 300
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bits", [8, 16])
 def test_frames_cut_into_several_launches_equal_one_launch(bits):
     """Frames whose draws fall into both kernel classes are cut into runs, one launch each, with the live surfaces
@@ -215,7 +263,7 @@ def test_frames_cut_into_several_launches_equal_one_launch(bits):
             finally:
                 L.cghip_debug_force_general_kernel(0)
             before = m.device_info()["kernel_launches"]
-            K.set_cut_policy(cut_cost_scale=0.0, max_segments=64)
+            K.set_cut_policy(cut_cost_scale=0.0, max_segments=64, sampled_fast=False)
             try:
                 cut = S.run_product(sc, mixer=m, planes_cache=cache)
             finally:

@@ -277,6 +277,28 @@ def test_fast_class_fuzz_scenes_are_planned_for_the_fast_kernel(full):
     assert (n_full > 30) if full else (n_full == 0)
 
 
+@pytest.mark.parametrize("bits", [8, 16])
+def test_box_fuzz_scenes_are_planned_for_the_fast_kernels_sampled_bodies(bits):
+    """Picture-in-picture boxes and 1:1 layers off the 4-pixel grid are the fast kernel's own (FC_SAMPLED): the GPU
+    test over these scenes (tests/test_fuzz.py) only means something if the planner sends them there."""
+    from fuzz_scenes import fuzz_box_scene
+    n_sampled = n_axis = n_unit = 0
+    for seed in range(100):
+        sc = fuzz_box_scene(seed, bits, seed % 2 == 1)
+        _d, _s, ops, _full = product_plan(sc)
+        assert K.last_plan_fast or not ops, (seed, [(o.kind, o.fast_class, hex(o.flags)) for o in ops])
+        for o in ops:
+            if o.kind == K.KOP_DRAW_PLANES and o.fast_class == K.FC_SAMPLED:
+                n_sampled += 1
+                base = 16 if o.planes[0].bits == 16 else 12
+                assert base <= o.fetch_body < base + 4 and not o.flags & K.KF_INVERT
+                assert all(o.planes[n].w >= 2 for n in range(o.nplanes))
+                assert bool(o.flags & K.KF_UNIT_SCALE) == bool((o.fetch_body - base) & 2)
+                n_unit += bool(o.flags & K.KF_UNIT_SCALE)
+                n_axis += bool(o.flags & K.KF_AXIS)
+    assert n_sampled > 150 and n_axis > 100 and n_unit > 20, (n_sampled, n_axis, n_unit)
+
+
 # ---------------------------------------------------------------- frames cut into several launches (segments)
 
 def check_segments(ops, segs, W, H):
@@ -347,6 +369,17 @@ def plan_with_segments(sc):
 
 def test_a_scaled_box_between_full_screen_layers_gets_its_own_small_launch():
     W, H = 1920, 1080
+    # today the box is sampled by the 4-pixels-per-lane kernel itself: one launch
+    ops, segs = plan_with_segments(mixed_scene(W, H))
+    assert [s["fast"] for s in segs] == [1] and ops[6].fast_class == K.FC_SAMPLED
+    try:
+        K.set_cut_policy(sampled_fast=False)
+        _scaled_box_cases(W, H)
+    finally:
+        K.set_cut_policy()
+
+
+def _scaled_box_cases(W, H):
     ops, segs = plan_with_segments(mixed_scene(W, H))
     assert [s["fast"] for s in segs] == [1, 0, 1]
     check_segments(ops, segs, W, H)
@@ -364,12 +397,9 @@ def test_a_scaled_box_between_full_screen_layers_gets_its_own_small_launch():
     # small frames are launch-bound: never cut
     ops, segs = plan_with_segments(mixed_scene(96, 64))
     assert len(segs) == 1
-    try:
-        K.set_cut_policy(max_segments=1)
-        ops, segs = plan_with_segments(mixed_scene(W, H))
-        assert len(segs) == 1 and not segs[0]["fast"]
-    finally:
-        K.set_cut_policy()
+    K.set_cut_policy(max_segments=1, sampled_fast=False)
+    ops, segs = plan_with_segments(mixed_scene(W, H))
+    assert len(segs) == 1 and not segs[0]["fast"]
 
 
 def test_empty_scene_is_one_launch_that_stores_the_frame():
@@ -386,7 +416,7 @@ def test_fuzz_scenes_cut_at_every_class_change_hand_surfaces_over_correctly(bits
     from fuzz_scenes import fuzz_scene, fuzz_fast_scene
     n_cut = n_spill = 0
     try:
-        K.set_cut_policy(cut_cost_scale=0.0, max_segments=64)
+        K.set_cut_policy(cut_cost_scale=0.0, max_segments=64, sampled_fast=False)
         for seed in range(300):
             sc = fuzz_scene(seed, bits) if seed % 3 else fuzz_fast_scene(seed, bits, True)
             ops, segs = plan_with_segments(sc)

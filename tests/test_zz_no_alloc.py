@@ -50,7 +50,7 @@ def test_noalloc_entry_point_equals_render_async_on_two_calls_in_a_row():
     import torch
     import server_amd as A
     m = A.Mixer(channel_id=21, gpu=0)
-    K.set_cut_policy(cut_cost_scale=0.0, max_segments=64)  # cut wherever the kernel class changes
+    K.set_cut_policy(cut_cost_scale=0.0, max_segments=64, sampled_fast=False)  # cut wherever the kernel class changes
     try:
         first = True
         for (W, H, bits, n_fill) in ((1024, 360, 16, 3), (320, 96, 8, 1)):  # the second call is the smaller one
@@ -78,7 +78,7 @@ def test_noalloc_entry_point_refuses_what_does_not_fit():
     import torch
     import server_amd as A
     m = A.Mixer(channel_id=22, gpu=0)
-    K.set_cut_policy(cut_cost_scale=0.0, max_segments=64)
+    K.set_cut_policy(cut_cost_scale=0.0, max_segments=64, sampled_fast=False)
     try:
         W, H = 3840, 2160  # hand-over surfaces of a cut 2160p 16-bit frame: 2 x 66 MB + keys > 48 MiB of scratch
         sc = _mixed_scene(W, H, 16, 1)
