@@ -227,7 +227,7 @@ def test_fast_kernel_samples_boxes_like_the_general_kernel(bits, full):
                 # blend-mode layers divide by the box edge's small alpha (shader.frag:427-428), and the probes find
                 # most but not every such pixel (measured worst: tests/golden/parity16_report.json)
                 st = P16.check(sc, fast, ref, cache, unexplained_fraction=2e-4)
-                assert st["gt2"] <= 0.15 and st["max_outside_amplifying"] <= 32, (seed, st)
+                assert st["gt2"] <= 0.15 and st["max_outside_amplifying"] <= 16, (seed, st)  # measured worst: 10
                 key = "fuzz_box_300_scenes_16bit" + ("_with_temporaries" if full else "")
                 w = P16.REPORT.setdefault(key, {"max": 0, "gt2": 0.0, "max_outside_amplifying": 0, "scenes_beyond_2": 0})
                 w["max"], w["gt2"] = max(w["max"], st["max"]), max(w["gt2"], st["gt2"])
