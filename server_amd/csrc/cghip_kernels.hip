@@ -1192,6 +1192,11 @@ DEV int opaque_s(int v)
     asm volatile("" : "+s"(v));
     return v;
 }
+DEV int opaque_v(int v) /* the same for a per-lane value */
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
 DEV float in_vgpr(float x)
 {
     asm volatile("" : "+v"(x));
@@ -2012,37 +2017,39 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                     static_for<0, P>([&](auto I) { col[decltype(I)::value] = f4{0, 0, 0, 0}; }); /* never planned */
                 }
                 break;
+            /* sampled bodies: like the aligned ones, each starts from opaque copies of its row and column, or the
+               compiler evaluates every body's coordinate arithmetic in front of the switch for every op */
             case FB_RECT8 + 0:
                 if constexpr (SAMPLED)
-                    fetch_rect8<false, false>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect8<false, false>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT8 + 1:
                 if constexpr (SAMPLED)
-                    fetch_rect8<true, false>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect8<true, false>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT8 + 2:
                 if constexpr (SAMPLED)
-                    fetch_rect8<false, true>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect8<false, true>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT8 + 3:
                 if constexpr (SAMPLED)
-                    fetch_rect8<true, true>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect8<true, true>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT16 + 0:
                 if constexpr (SAMPLED)
-                    fetch_rect16<false, false>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect16<false, false>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT16 + 1:
                 if constexpr (SAMPLED)
-                    fetch_rect16<true, false>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect16<true, false>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT16 + 2:
                 if constexpr (SAMPLED)
-                    fetch_rect16<false, true>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect16<false, true>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT16 + 3:
                 if constexpr (SAMPLED)
-                    fetch_rect16<true, true>(op, load_hot_g(op), px0, y, col, cover);
+                    fetch_rect16<true, true>(op, load_hot_g(op), opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_PACKED8: fetch_packed<8>(h, sx, SY, col); break;
             case FB_PACKED16: fetch_packed<16>(h, sx, SY, col); break;

@@ -634,7 +634,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         /* tests/gpu_probe.py, 16 layers 2160p 8-bit, ps per pixel of the draw's box. General kernel: axis-aligned 4.6 -
            4.9, perspective 5.4, rotated 6.3, composite of a temporary with a blend mode 4.4. Fast kernel: aligned 1:1
            1.9 (16-bit 1.6), sampled box of planes 3.5 (5.0 into a temporary, where the kernel holds 128 registers),
-           of a packed plane 2.6 (16-bit planes: 4.7 and 3.7), composite of a temporary 3.3. */
+           of a packed plane 2.6 (16-bit planes: 3.9 and 3.2), composite of a temporary 3.3. */
         /* gap: what a cut costs beyond the bytes. Two launches back to back are 6 us apart, but the general kernel's time
            is not proportional to its draws' pixels (every wave pays set-up, surface loads and stores): BASELINE config 2
            cut in two - the first three layers to the fast kernel, predicted gain 7 us - ran 0.102 ms against 0.086 ms in
@@ -645,7 +645,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             if (k == 0)
                 return o.kind == KOP_DRAW_SURFACE ? 4.4 : (planes && !(o.flags & KF_RECT)) ? 6.0 : 4.8;
             if (planes && o.fetch_body >= FB_RECT8)
-                return ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.35 : 1.0) + (temp ? 1.5 : 0.0);
+                return ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.15 : 1.0) + (temp ? 1.5 : 0.0);
             if (o.kind == KOP_DRAW_SURFACE)
                 return o.blend_mode != 0 ? 3.3 : 1.9;
             return fmt.bits == 16 ? 1.6 : 1.9;
