@@ -24,7 +24,9 @@ for (W, H, bits) in ((3840, 2160, 16), (1920, 1080, 8)):
         for n in (1, 2, 3, 4, 8):
             sc = mixed(W, H, bits, n, box)
             row = []
-            for name, policy in (("general", None), ("policy", (1.0, 8)), ("cut", (0.0, 8))):
+            # "policy": today the box is sampled by the 4-pixels-per-lane kernel itself (one launch); "cut": the round-1
+            # plan, the box in a launch of the general kernel of its own between two launches of the fast one
+            for name, policy in (("general", None), ("policy", (1.0, 8)), ("cut", (1.0, 8, False))):
                 if policy is None:
                     L.cghip_debug_force_general_kernel(1)
                 else:
