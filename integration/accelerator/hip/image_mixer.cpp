@@ -3,7 +3,7 @@
  *
  * ADAPTER SOURCE, NOT COMPILED IN THIS REPOSITORY (needs the reference's headers and boost; see image_mixer.h). The
  * compiled and tested twin is server_amd/host/image_mixer.cpp; the two differ only in the types named in
- * INTEGRATION.md section 6 (boost::any opaque, array<> storage, caspar exceptions, spl::shared_ptr).
+ * INTEGRATION.md section 2a (boost::any opaque, array<> storage, caspar exceptions, spl::shared_ptr).
  *
  * Structure follows accelerator/ogl/image/image_mixer.cpp (GPLv3, (c) Sveriges Television AB) function for function:
  * the transform stack and layer tree (:54-72, :247-299) are the same code because they ARE the interface contract; the

@@ -9,6 +9,14 @@
  * What changes: the draws are not executed one by one; they are flattened into a cghip_draw list and
  * handed to cghip_mixer_render_async, which fuses them into one kernel launch. Temporaries become
  * surface slot numbers.
+ *
+ * Provenance: this file is the adapter between CasparCG Server's plugin interface and the C ABI, and three pieces of
+ * it restate the reference's own logic closely, on purpose, identifier names included, so that the adapter behaves like
+ * the code it replaces: image_transform::operator*= (core/frame/frame_transform.cpp:53-108), the item / layer structs
+ * (accelerator/ogl/image/image_mixer.cpp:54-72) and push / visit / pop (:247-299). CasparCG Server is Copyright (c)
+ * Sveriges Television AB and licensed under the GNU General Public License v3 or later; those restated parts, and this
+ * adapter as a derived work meant to be compiled into the reference tree (integration/), fall under the same licence.
+ * Everything below the C ABI (server_amd/csrc) has no counterpart in the reference.
  */
 #include "image_mixer.h"
 
