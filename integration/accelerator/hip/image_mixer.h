@@ -40,7 +40,7 @@ class image_mixer final : public core::image_mixer
     void pop() override;
 
     /* Extensions the unchanged caller never uses (core/mixer/mixer.cpp:78-79 builds an 8-bit bgra desc):
-       16-bit BGRA output and an in-kernel field mask. See INTEGRATION.md section 6 for where a channel would set them. */
+       16-bit BGRA output and an in-kernel field mask. See INTEGRATION.md section 2a for where a channel would set them. */
     void set_output_bits(int bits);       // 8 (default, the reference's output) or 16
     void set_field_mode(int field_mode);  // 0 progressive (default), 1 / 2: only even / odd rows are drawn
 
