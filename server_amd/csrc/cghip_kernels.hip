@@ -838,18 +838,21 @@ struct HotG {
     int32_t  w0, h0, w1, h1;
     float    fw0, fh0, fw1, fh1;
     int32_t  bits0;
+    int32_t  fused, ax0, ay0, ax1, ay1; /* KOp::fused: x0..y1 is the composite's box, ax0..ay1 the item's */
 };
 DEV HotG load_hot_g(const KOp& op)
 {
     HotG h = {op.kind, op.flags, op.dst, op.src_surface, op.local_key, op.layer_key, op.pixel_format, op.x0, op.y0, op.x1,
               op.y1, op.unit_dx, op.unit_dy, op.sample_class, (uint64_t)op.planes[0].ptr, (uint64_t)op.planes[1].ptr,
               (uint64_t)op.planes[2].ptr, (uint64_t)op.planes[3].ptr, op.planes[0].w, op.planes[0].h, op.planes[1].w,
-              op.planes[1].h, op.planes[0].fw, op.planes[0].fh, op.planes[1].fw, op.planes[1].fh, op.planes[0].bits};
+              op.planes[1].h, op.planes[0].fw, op.planes[0].fh, op.planes[1].fw, op.planes[1].fh, op.planes[0].bits,
+              op.fused, op.ax0, op.ay0, op.ax1, op.ay1};
     asm volatile(""
                  : "+s"(h.kind), "+s"(h.flags), "+s"(h.dst), "+s"(h.src_surface), "+s"(h.local_key), "+s"(h.layer_key),
                    "+s"(h.pixel_format), "+s"(h.x0), "+s"(h.y0), "+s"(h.x1), "+s"(h.y1), "+s"(h.unit_dx), "+s"(h.unit_dy),
                    "+s"(h.sample_class), "+s"(h.ptr0), "+s"(h.ptr1), "+s"(h.ptr2), "+s"(h.ptr3), "+s"(h.w0), "+s"(h.h0),
-                   "+s"(h.w1), "+s"(h.h1), "+s"(h.fw0), "+s"(h.fh0), "+s"(h.fw1), "+s"(h.fh1), "+s"(h.bits0));
+                   "+s"(h.w1), "+s"(h.h1), "+s"(h.fw0), "+s"(h.fh0), "+s"(h.fw1), "+s"(h.fh1), "+s"(h.bits0),
+                   "+s"(h.fused), "+s"(h.ax0), "+s"(h.ay0), "+s"(h.ax1), "+s"(h.ay1));
     return h;
 }
 
@@ -1133,15 +1136,19 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
                 k1 = c4 ? 0.0f : k1;
             }
         }
-        /* cull against the op's touched box, then against the quad itself */
+        /* cull against the op's touched box, then against the quad itself (a fused op: the composite's box culls, the
+           item's own box and quad only decide whether its colour is zero) */
         bool live = !clr & (y >= h.y0) & (y < h.y1) & (x >= h.x0) & (x < h.x1);
         f4   color = {0, 0, 0, 0};
-        if (live) {
+        bool covered = live & (y >= h.ay0) & (y < h.ay1) & (x >= h.ax0) & (x < h.ax1);
+        if (covered) {
             if (h.kind == KOP_DRAW_SURFACE)
                 color = FULL ? sel4(h.src_surface == KS_RGBA2, s2, s1) : f4{0, 0, 0, 0};
             else
-                live = source_color(op, h, x, y, color);
+                covered = source_color(op, h, x, y, color);
         }
+        if (!h.fused)
+            live = covered;
         if (!live)
             continue;
 
@@ -1160,7 +1167,17 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
             f4         back = s0;
             if (FULL)
                 back = sel4(d1, s1, sel4(d2, s2, s0));
-            f4 res = shade(op, color, lkey, ykey, back);
+            f4 res;
+            if (h.fused) { /* wave-uniform. The item over the cleared layer texture, its UNORM store, the composite */
+                f4 t = shade(op, color, lkey, ykey, f4{0.0f, 0.0f, 0.0f, 0.0f});
+                t    = f4{quantize<BITS>(t.x), quantize<BITS>(t.y), quantize<BITS>(t.z), quantize<BITS>(t.w)};
+                t    = sel4(covered, t, f4{0.0f, 0.0f, 0.0f, 0.0f}); /* outside the item the texture is still zero */
+                const BlendArgs b = {op.b_flags, op.b_local_key, op.b_layer_key, op.b_opacity, op.b_blend_mode};
+                const float     bl = b.local_key == KS_KEY1 ? k1 : k0, by = b.layer_key == KS_KEY1 ? k1 : k0;
+                res = shade_blend<MODE_RUNTIME>(b, t, bl, by, back);
+            } else {
+                res = shade(op, color, lkey, ykey, back);
+            }
             res    = f4{quantize<BITS>(res.x), quantize<BITS>(res.y), quantize<BITS>(res.z), quantize<BITS>(res.w)};
             if (FULL) {
                 s1 = sel4(d1, res, s1);

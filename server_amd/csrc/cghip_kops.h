@@ -161,6 +161,16 @@ struct KOp {
        (cghip_kernels.hip: fetch_planar16r): aY, aR, cR, aGr, aGb, cG, aB, cB */
     float ycoef[8];
     int32_t fetch_body, blend_body; /* KFetchBody, KBlendBody (fast kernel) */
+    /* A blend-mode layer that holds ONE item is three reference draws: the layer texture is cleared, the item drawn
+       into it, and the texture composited over the target with the layer's mode (image_mixer.cpp:128-171,207-225).
+       The planner fuses them into this one op for the general kernel (cghip_plan.cpp: fuse_layers): the item's colour
+       goes through the UNORM store the texture would have given it, then through the composite's blend, and the
+       texture never exists. x0..y1 is then the COMPOSITE's box, ax0..ay1 the item's own; b_* are the composite's
+       keys, opacity, keyer / invert flags and mode. Unfused ops: fused = 0, ax0..ay1 = x0..y1. */
+    int32_t  fused, b_blend_mode, b_local_key, b_layer_key;
+    uint32_t b_flags;
+    float    b_opacity;
+    int32_t  ax0, ay0, ax1, ay1;
     KPlane  planes[4];
     KTri    tri[2];
 };

@@ -614,7 +614,8 @@ static uint32_t refs_of(const KOp& o) /* surfaces an op reads or writes */
     if (o.kind == KOP_CLEAR)
         return surf_bit(o.dst);
     return surf_bit(o.dst) | surf_bit(o.local_key) | surf_bit(o.layer_key) |
-           (o.kind == KOP_DRAW_SURFACE ? surf_bit(o.src_surface) : 0u);
+           (o.kind == KOP_DRAW_SURFACE ? surf_bit(o.src_surface) : 0u) |
+           (o.fused ? surf_bit(o.b_local_key) | surf_bit(o.b_layer_key) : 0u);
 }
 
 static void split_into_segments(const cghip_format& fmt, frame_plan* out)
@@ -759,6 +760,99 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
                 sg.gx0 = bx0, sg.gy0 = by0, sg.gx1 = bx1, sg.gy1 = by1;
         }
     }
+}
+
+/* ---- blend-mode layers with one item, in launches of the general kernel ----------------------------------------
+ * CLEAR T; item -> T; composite T -> D with the layer's mode: three ops, two of them walking a full register surface
+ * through per-lane selects, and a frame that needs the kernel variant with the RGBA temporaries. Fused (KOp::fused) the
+ * item's colour is blended over zero and rounded to the UNORM code the texture would have held - the same arithmetic
+ * with a literal zero background -, then goes through the composite's blend over D. Conditions: the item is the only
+ * draw into T since its CLEAR and sits right in front of the composite; nothing reads T afterwards before its next
+ * CLEAR; the composite has no colour adjustments (it never has: its transform is the default one). Done per launch,
+ * after the frame has been cut: only launches of the general kernel are rewritten (the 4-pixels-per-lane kernels keep
+ * their own composite body), and a pattern never straddles a cut. Exact: tests compare fused and unfused frames bit
+ * for bit (test hook cghip_debug_no_layer_fusion). BASELINE config 2: 20 ops -> 8. */
+static int g_no_layer_fusion = 0;
+
+static void fuse_layers(frame_plan* out)
+{
+    if (g_no_layer_fusion)
+        return;
+    std::vector<KOp>     fused_ops;
+    std::vector<segment> segs = out->segments;
+    fused_ops.reserve(out->ops.size());
+    bool any = false;
+    for (segment& sg : segs) {
+        const int first = sg.first, end = sg.first + sg.count;
+        sg.first        = (int)fused_ops.size();
+        if (sg.fast) {
+            fused_ops.insert(fused_ops.end(), out->ops.begin() + first, out->ops.begin() + end);
+            sg.count = (int)fused_ops.size() - sg.first;
+            continue;
+        }
+        std::vector<KOp>  run(out->ops.begin() + first, out->ops.begin() + end);
+        std::vector<char> drop(run.size(), 0);
+        const int         n = (int)run.size();
+        for (int j = 1; j < n; ++j) {
+            const KOp& B = run[(size_t)j];
+            KOp&       A = run[(size_t)j - 1];
+            if (B.kind != KOP_DRAW_SURFACE || A.kind != KOP_DRAW_PLANES || drop[(size_t)j - 1])
+                continue;
+            const int T = B.src_surface;
+            if ((T != KS_RGBA1 && T != KS_RGBA2) || A.dst != T || B.dst == T || A.fused || A.blend_mode != 0)
+                continue;
+            if (B.flags & (KF_LEVELS | KF_CSB | KF_CHROMA))
+                continue;
+            /* the item is the only draw into T since T's CLEAR, which is in this launch */
+            int c = j - 2;
+            for (; c >= 0; --c) {
+                const KOp& o = run[(size_t)c];
+                if (drop[(size_t)c])
+                    continue;
+                if (o.kind == KOP_CLEAR && o.dst == T)
+                    break;
+                if (refs_of(o) & surf_bit(T))
+                    c = -1;
+            }
+            if (c < 0)
+                continue;
+            /* nothing looks at T after the composite before T is cleared again (whole frame, not only this launch) */
+            bool dead = true;
+            for (int k = first + j + 1; k < (int)out->ops.size() && dead; ++k) {
+                const KOp& o = out->ops[(size_t)k];
+                if (o.kind == KOP_CLEAR && o.dst == T)
+                    break;
+                dead = !(refs_of(o) & surf_bit(T));
+            }
+            if (!dead)
+                continue;
+            KOp F = A;
+            F.fused = 1;
+            F.ax0 = A.x0, F.ay0 = A.y0, F.ax1 = A.x1, F.ay1 = A.y1;
+            F.x0 = B.x0, F.y0 = B.y0, F.x1 = B.x1, F.y1 = B.y1;
+            F.dst = B.dst;
+            F.b_blend_mode = B.blend_mode, F.b_local_key = B.local_key, F.b_layer_key = B.layer_key;
+            F.b_flags = B.flags, F.b_opacity = B.opacity;
+            F.fast_class = FC_NONE;
+            run[(size_t)j]     = F;
+            drop[(size_t)j - 1] = 1;
+            drop[(size_t)c]     = 1; /* T's CLEAR: nothing between it and the composite touched T but the item */
+            any                 = true;
+        }
+        for (int i = 0; i < n; ++i)
+            if (!drop[(size_t)i])
+                fused_ops.push_back(run[(size_t)i]);
+        sg.count = (int)fused_ops.size() - sg.first;
+        uint32_t touched = 0;
+        for (int i = sg.first; i < sg.first + sg.count; ++i)
+            touched |= refs_of(fused_ops[(size_t)i]);
+        sg.full = (touched & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0 ||
+                  ((sg.load_mask | sg.store_mask) & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0;
+    }
+    if (!any)
+        return;
+    out->ops      = std::move(fused_ops);
+    out->segments = std::move(segs);
 }
 
 /* Per launch: which of its ops can touch which band of the frame. The kernels used to walk the whole op list in
@@ -923,6 +1017,8 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
                 continue;
         }
         drawn[op.dst].add(op.x0, op.y0, op.x1, op.y1);
+        op.ax0 = op.x0, op.ay0 = op.y0, op.ax1 = op.x1, op.ay1 = op.y1;
+        op.b_local_key = op.b_layer_key = KS_NONE;
         classify_sampling(op);
         classify_fast(op, fmt->width); /* dst is known now */
         out->ops.push_back(op);
@@ -936,6 +1032,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
             out->fast = false;
     drop_hidden_ops(*fmt, out);
     split_into_segments(*fmt, out);
+    fuse_layers(out);
     op_masks(*fmt, out);
     return CGHIP_OK;
 }
@@ -969,6 +1066,8 @@ extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_genera
 extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling = on; }
 /* sampled (scaled / rotated / perspective) draws stay with the 1-pixel-per-lane kernel, as before FC_SAMPLED existed */
 extern "C" void cghip_debug_no_sampled_fast(int on) { cghip::g_no_sampled_fast = on; }
+/* blend-mode layers with one item stay three ops (CLEAR, item, composite) in launches of the general kernel */
+extern "C" void cghip_debug_no_layer_fusion(int on) { cghip::g_no_layer_fusion = on; }
 extern "C" void cghip_debug_keep_hidden_ops(int on) { cghip::g_keep_hidden_ops = on; }
 extern "C" void cghip_debug_full_frame_composites(int on) { cghip::g_full_frame_composites = on; }
 extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }

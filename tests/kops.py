@@ -28,6 +28,9 @@ class KOp(C.Structure):
         ("fast_class", C.c_int32), ("ch_inv_spill", C.c_float), ("ch_inv_soft", C.c_float), ("sample_class", C.c_int32),
         ("csx", C.c_int32), ("csy", C.c_int32), ("lv_range", C.c_float), ("ch_soft_range", C.c_float),
         ("ycoef", C.c_float * 8), ("fetch_body", C.c_int32), ("blend_body", C.c_int32),
+        ("fused", C.c_int32), ("b_blend_mode", C.c_int32), ("b_local_key", C.c_int32), ("b_layer_key", C.c_int32),
+        ("b_flags", C.c_uint32), ("b_opacity", C.c_float),
+        ("ax0", C.c_int32), ("ay0", C.c_int32), ("ax1", C.c_int32), ("ay1", C.c_int32),
         ("planes", KPlane * 4), ("tri", KTri * 2),
     ]
 

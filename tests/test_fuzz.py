@@ -240,6 +240,44 @@ def test_fast_kernel_samples_boxes_like_the_general_kernel(bits, full):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits", [8, 16])
+def test_fused_blend_layers_equal_the_three_draws(bits):
+    """A blend-mode layer with one item is ONE op in launches of the general kernel (cghip_plan.cpp: fuse_layers): the
+    item's colour goes through the UNORM store the layer texture would have given it and then through the composite.
+    Same arithmetic in the same order, so the frame must equal the unfused plan bit for bit at both depths - with the
+    general kernel forced, so that every blend-mode layer of the fuzz scenes takes that path - and BASELINE config 2 at
+    full size as the planner runs it."""
+    import server_amd as A
+    from fuzz_scenes import fuzz_scene, fuzz_fast_scene, fuzz_box_scene
+    m = A.Mixer(channel_id=8, gpu=0)
+    L = A.lib()
+    n_fused = 0
+    try:
+        scenes = [fuzz_scene(seed, bits) for seed in range(200)] + [fuzz_fast_scene(seed, bits, True) for seed in range(100)] + \
+                 [fuzz_box_scene(seed, bits, True) for seed in range(100)] + ([S.config2()] if bits == 8 else [])
+        for sc in scenes:
+            cache = {}
+            forced = sc["name"] != "config2"
+            L.cghip_debug_force_general_kernel(1 if forced else 0)
+            try:
+                before = m.device_info()["kernel_launches"]
+                fused = S.run_product(sc, mixer=m, planes_cache=cache)
+                assert m.device_info()["kernel_launches"] - before == 1
+                L.cghip_debug_no_layer_fusion(1)
+                try:
+                    plain = S.run_product(sc, mixer=m, planes_cache=cache)
+                finally:
+                    L.cghip_debug_no_layer_fusion(0)
+            finally:
+                L.cghip_debug_force_general_kernel(0)
+            assert np.array_equal(fused, plain), (sc["name"], S.diff_stats(fused, plain))
+            n_fused += any(o[0] == "push" and o[1].get("blend_mode", "normal") != "normal" for o in sc["ops"])
+    finally:
+        m.close()
+    assert n_fused > 100, n_fused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
 def test_frames_cut_into_several_launches_equal_one_launch(bits):
     """Frames whose draws fall into both kernel classes are cut into runs, one launch each, with the live surfaces
     handed over through HBM as UNORM codes (cghip_plan.cpp: split_into_segments). With the cut cost forced to zero the

@@ -335,6 +335,10 @@ def check_segments(ops, segs, W, H):
             if boxed:
                 assert sg["gx0"] <= o.x0 and o.x1 <= sg["gx1"] and sg["gy0"] <= o.y0 and o.y1 <= sg["gy1"]
             reads = [o.dst, o.local_key, o.layer_key] + ([o.src_surface] if o.kind == K.KOP_DRAW_SURFACE else [])
+            if o.fused:  # a blend-mode layer with one item as ONE op: the composite's keys are read too
+                reads += [o.b_local_key, o.b_layer_key]
+                assert not sg["fast"] and o.kind == K.KOP_DRAW_PLANES and o.dst not in (1, 2)
+                assert o.x0 <= o.ax0 and o.ax1 <= o.x1 and o.y0 <= o.ay0 and o.ay1 <= o.y1
             for s in reads:
                 if s >= 0:
                     assert regs[s] == true[s], (si, s, "stale surface")
@@ -400,6 +404,30 @@ def _scaled_box_cases(W, H):
     K.set_cut_policy(max_segments=1, sampled_fast=False)
     ops, segs = plan_with_segments(mixed_scene(W, H))
     assert len(segs) == 1 and not segs[0]["fast"]
+
+
+def test_blend_mode_layers_with_one_item_are_fused_in_general_launches():
+    """BASELINE config 2: six of its eight layers are blend-mode layers holding one item: CLEAR, item -> layer
+    texture, composite with the mode. In a launch of the general kernel each triple becomes ONE op (KOp::fused), the
+    layer texture never exists and the launch no longer needs the kernel variant with the RGBA temporaries."""
+    import server_amd as A
+    sc = S.config2()
+    ops, segs = plan_with_segments(sc)
+    assert len(segs) == 1 and not segs[0]["fast"] and not segs[0]["full"]
+    assert len(ops) == 8 and sum(o.fused for o in ops) == 6 and all(o.kind == K.KOP_DRAW_PLANES and o.dst == 0 for o in ops)
+    for o in ops:
+        if o.fused:
+            assert o.b_blend_mode != 0 and o.blend_mode == 0 and o.b_opacity == 1.0
+    check_segments(ops, segs, sc["width"], sc["height"])
+    A.lib().cghip_debug_no_layer_fusion(1)
+    try:
+        ops3, segs3 = plan_with_segments(sc)
+        assert len(ops3) == 20 and segs3[0]["full"] and not any(o.fused for o in ops3)
+    finally:
+        A.lib().cghip_debug_no_layer_fusion(0)
+    # a MIX pair shares its texture between two items: not fused; the fast kernels keep their own composite body
+    ops4, segs4 = plan_with_segments(S.config4())
+    assert not any(o.fused for o in ops4) and segs4[0]["fast"] and segs4[0]["full"]
 
 
 def test_empty_scene_is_one_launch_that_stores_the_frame():
