@@ -117,7 +117,8 @@ struct segment {
     int      first = 0, count = 0; /* ops[first, first + count) */
     bool     fast = false;         /* cghip_composite_fast, else cghip_composite */
     bool     full = false;         /* touches RGBA1 / RGBA2 */
-    bool     sampled = false;      /* fast, and a draw takes a sampled fetch body (FB_RECT8) */
+    bool     fused = false;        /* holds a KOp::fused op */
+    int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
     int      gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0; /* pixel box the launch covers */
     /* op masks per band of the frame (KSpill::masks): offset into frame_plan::masks, in uint64 */

@@ -64,7 +64,8 @@ enum KBlendBody : int32_t {
     BB_RGBA_GENERAL = 2,
     BB_KEY_SIMPLE   = 3, /* into a key surface */
     BB_KEY_GENERAL  = 4,
-    BB_MODE         = 5  /* a temporary composited with a blend mode */
+    BB_MODE         = 5, /* a temporary composited with a blend mode */
+    BB_FUSED        = 6  /* KOp::fused: the item over zero, its UNORM store, the composite's blend mode */
 };
 
 /* How cghip_composite samples a KOP_DRAW_PLANES source (host classification, cghip_plan.cpp). The two common
@@ -109,6 +110,7 @@ struct KSpill {
     const uint64_t* masks;
     int32_t  ncols, nrows, nchunks, col_shift;
     int32_t  dense; /* every op is in every band (full-screen stacks): the table is not read */
+    int32_t  fused; /* the launch holds a fused blend-mode layer (KOp::fused): picks the general kernel's instance */
 };
 
 struct KPlane {
@@ -163,7 +165,7 @@ struct KOp {
     int32_t fetch_body, blend_body; /* KFetchBody, KBlendBody (fast kernel) */
     /* A blend-mode layer that holds ONE item is three reference draws: the layer texture is cleared, the item drawn
        into it, and the texture composited over the target with the layer's mode (image_mixer.cpp:128-171,207-225).
-       The planner fuses them into this one op for the general kernel (cghip_plan.cpp: fuse_layers): the item's colour
+       The planner fuses them into this one op (cghip_plan.cpp: fuse_layers): the item's colour
        goes through the UNORM store the texture would have given it, then through the composite's blend, and the
        texture never exists. x0..y1 is then the COMPOSITE's box, ax0..ay1 the item's own; b_* are the composite's
        keys, opacity, keyer / invert flags and mode. Unfused ops: fused = 0, ax0..ay1 = x0..y1. */

@@ -643,13 +643,14 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         const double rt_px = fmt.bits == 16 ? 3.1 : 1.6, gap = 15e6;
         auto per_px = [&](const KOp& o, int k) -> double {
             const bool planes = o.kind == KOP_DRAW_PLANES, temp = o.dst == KS_RGBA1 || o.dst == KS_RGBA2;
+            const double fused = o.fused ? (k == 0 ? 1.5 : 1.7) : 0.0; /* the composite that rides on the item */
             if (k == 0)
-                return o.kind == KOP_DRAW_SURFACE ? 4.4 : (planes && !(o.flags & KF_RECT)) ? 6.0 : 4.8;
+                return (o.kind == KOP_DRAW_SURFACE ? 4.4 : (planes && !(o.flags & KF_RECT)) ? 6.0 : 4.8) + fused;
             if (planes && o.fetch_body >= FB_RECT8)
-                return ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.15 : 1.0) + (temp ? 1.5 : 0.0);
+                return ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.15 : 1.0) + (temp ? 1.5 : 0.0) + fused;
             if (o.kind == KOP_DRAW_SURFACE)
                 return o.blend_mode != 0 ? 3.3 : 1.9;
-            return fmt.bits == 16 ? 1.6 : 1.9;
+            return (fmt.bits == 16 ? 1.6 : 1.9) + fused;
         };
         /* into the fast kernel the whole frame makes the trip; into the general one, which may cover only the box of
            its draws, this draw's box stands in for that */
@@ -733,9 +734,15 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
                 later |= refs_of(ops[(size_t)i]) & ~reset;
         }
         sg.full       = (touched & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0;
-        sg.sampled    = false;
-        for (int i = sg.first; i < sg.first + sg.count && sg.fast; ++i)
-            sg.sampled = sg.sampled || (ops[(size_t)i].kind == KOP_DRAW_PLANES && ops[(size_t)i].fetch_body >= FB_RECT8);
+        sg.ext        = 0;
+        sg.fused      = false;
+        for (int i = sg.first; i < sg.first + sg.count; ++i)
+            sg.fused = sg.fused || ops[(size_t)i].fused != 0;
+        for (int i = sg.first; i < sg.first + sg.count && sg.fast; ++i) {
+            const KOp& o = ops[(size_t)i];
+            if (o.kind == KOP_DRAW_PLANES)
+                sg.ext = std::max(sg.ext, o.fused ? 2 : o.fetch_body >= FB_RECT8 ? 1 : 0);
+        }
         sg.load_mask  = touched & in_mem;
         sg.store_mask = written & ~zero & later;
         if (si == 0)
@@ -768,91 +775,92 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
  * item's colour is blended over zero and rounded to the UNORM code the texture would have held - the same arithmetic
  * with a literal zero background -, then goes through the composite's blend over D. Conditions: the item is the only
  * draw into T since its CLEAR and sits right in front of the composite; nothing reads T afterwards before its next
- * CLEAR; the composite has no colour adjustments (it never has: its transform is the default one). Done per launch,
- * after the frame has been cut: only launches of the general kernel are rewritten (the 4-pixels-per-lane kernels keep
- * their own composite body), and a pattern never straddles a cut. Exact: tests compare fused and unfused frames bit
+ * CLEAR; the composite has no colour adjustments (it never has: its transform is the default one). Done before the
+ * frame is cut into launches: a fused op is one op for either kernel, and a frame whose blend-mode layers all hold one
+ * item no longer needs the kernel variants with the RGBA temporaries. Exact: tests compare fused and unfused frames bit
  * for bit (test hook cghip_debug_no_layer_fusion). BASELINE config 2: 20 ops -> 8. */
 static int g_no_layer_fusion = 0;
 
-static void fuse_layers(frame_plan* out)
+static void fuse_layers(const cghip_format& fmt, frame_plan* out)
 {
     if (g_no_layer_fusion)
         return;
-    std::vector<KOp>     fused_ops;
-    std::vector<segment> segs = out->segments;
-    fused_ops.reserve(out->ops.size());
-    bool any = false;
-    for (segment& sg : segs) {
-        const int first = sg.first, end = sg.first + sg.count;
-        sg.first        = (int)fused_ops.size();
-        if (sg.fast) {
-            fused_ops.insert(fused_ops.end(), out->ops.begin() + first, out->ops.begin() + end);
-            sg.count = (int)fused_ops.size() - sg.first;
+    std::vector<KOp>& ops = out->ops;
+    const int         n   = (int)ops.size();
+    std::vector<char> drop((size_t)n, 0);
+    bool              any = false;
+    for (int j = 1; j < n; ++j) {
+        const KOp& B = ops[(size_t)j];
+        const KOp& A = ops[(size_t)j - 1];
+        if (B.kind != KOP_DRAW_SURFACE || A.kind != KOP_DRAW_PLANES || drop[(size_t)j - 1])
             continue;
+        const int T = B.src_surface;
+        if ((T != KS_RGBA1 && T != KS_RGBA2) || A.dst != T || B.dst == T || A.fused || A.blend_mode != 0)
+            continue;
+        if (B.flags & (KF_LEVELS | KF_CSB | KF_CHROMA))
+            continue;
+        /* the item is the only draw into T since T's CLEAR */
+        int c = j - 2;
+        for (; c >= 0; --c) {
+            const KOp& o = ops[(size_t)c];
+            if (drop[(size_t)c])
+                continue;
+            if (o.kind == KOP_CLEAR && o.dst == T)
+                break;
+            if (refs_of(o) & surf_bit(T))
+                c = -1;
         }
-        std::vector<KOp>  run(out->ops.begin() + first, out->ops.begin() + end);
-        std::vector<char> drop(run.size(), 0);
-        const int         n = (int)run.size();
-        for (int j = 1; j < n; ++j) {
-            const KOp& B = run[(size_t)j];
-            KOp&       A = run[(size_t)j - 1];
-            if (B.kind != KOP_DRAW_SURFACE || A.kind != KOP_DRAW_PLANES || drop[(size_t)j - 1])
-                continue;
-            const int T = B.src_surface;
-            if ((T != KS_RGBA1 && T != KS_RGBA2) || A.dst != T || B.dst == T || A.fused || A.blend_mode != 0)
-                continue;
-            if (B.flags & (KF_LEVELS | KF_CSB | KF_CHROMA))
-                continue;
-            /* the item is the only draw into T since T's CLEAR, which is in this launch */
-            int c = j - 2;
-            for (; c >= 0; --c) {
-                const KOp& o = run[(size_t)c];
-                if (drop[(size_t)c])
-                    continue;
-                if (o.kind == KOP_CLEAR && o.dst == T)
-                    break;
-                if (refs_of(o) & surf_bit(T))
-                    c = -1;
-            }
-            if (c < 0)
-                continue;
-            /* nothing looks at T after the composite before T is cleared again (whole frame, not only this launch) */
-            bool dead = true;
-            for (int k = first + j + 1; k < (int)out->ops.size() && dead; ++k) {
-                const KOp& o = out->ops[(size_t)k];
-                if (o.kind == KOP_CLEAR && o.dst == T)
-                    break;
-                dead = !(refs_of(o) & surf_bit(T));
-            }
-            if (!dead)
-                continue;
-            KOp F = A;
-            F.fused = 1;
-            F.ax0 = A.x0, F.ay0 = A.y0, F.ax1 = A.x1, F.ay1 = A.y1;
-            F.x0 = B.x0, F.y0 = B.y0, F.x1 = B.x1, F.y1 = B.y1;
-            F.dst = B.dst;
-            F.b_blend_mode = B.blend_mode, F.b_local_key = B.local_key, F.b_layer_key = B.layer_key;
-            F.b_flags = B.flags, F.b_opacity = B.opacity;
+        if (c < 0)
+            continue;
+        /* nothing looks at T after the composite before T is cleared again */
+        bool dead = true;
+        for (int k = j + 1; k < n && dead; ++k) {
+            const KOp& o = ops[(size_t)k];
+            if (o.kind == KOP_CLEAR && o.dst == T)
+                break;
+            dead = !(refs_of(o) & surf_bit(T));
+        }
+        if (!dead)
+            continue;
+        /* The 4-pixels-per-lane kernels run a fused op (blend body BB_FUSED) when the lanes of the composite's box are
+           the lanes that touch the item's box - the composite was shrunk to the item's box widened to 4-pixel columns
+           (plan_frame; not for the HSL modes, whose composite covers the frame) - and the mode is a real one. An item
+           of their class that does not meet this stays three ops: fused it would belong to the general kernel. */
+        const bool same_lanes = B.x0 == (A.x0 & ~3) && B.x1 == std::min(fmt.width, (A.x1 + 3) & ~3) && B.y0 == A.y0 && B.y1 == A.y1;
+        const bool fast_fused = A.fast_class != FC_NONE && same_lanes && B.blend_mode != 0 && B.dst >= KS_RGBA0 && B.dst <= KS_RGBA2;
+        if (A.fast_class != FC_NONE && !fast_fused)
+            continue;
+        KOp F = A;
+        F.fused = 1;
+        F.ax0 = A.x0, F.ay0 = A.y0, F.ax1 = A.x1, F.ay1 = A.y1;
+        F.x0 = B.x0, F.y0 = B.y0, F.x1 = B.x1, F.y1 = B.y1;
+        F.dst = B.dst;
+        F.b_blend_mode = B.blend_mode, F.b_local_key = B.local_key, F.b_layer_key = B.layer_key;
+        F.b_flags = B.flags, F.b_opacity = B.opacity;
+        if (fast_fused)
+            F.blend_body = BB_FUSED;
+        else
             F.fast_class = FC_NONE;
-            run[(size_t)j]     = F;
-            drop[(size_t)j - 1] = 1;
-            drop[(size_t)c]     = 1; /* T's CLEAR: nothing between it and the composite touched T but the item */
-            any                 = true;
-        }
-        for (int i = 0; i < n; ++i)
-            if (!drop[(size_t)i])
-                fused_ops.push_back(run[(size_t)i]);
-        sg.count = (int)fused_ops.size() - sg.first;
-        uint32_t touched = 0;
-        for (int i = sg.first; i < sg.first + sg.count; ++i)
-            touched |= refs_of(fused_ops[(size_t)i]);
-        sg.full = (touched & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0 ||
-                  ((sg.load_mask | sg.store_mask) & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0;
+        ops[(size_t)j]      = F;
+        drop[(size_t)j - 1] = 1;
+        drop[(size_t)c]     = 1; /* T's CLEAR: nothing between it and the composite touched T but the item */
+        any                 = true;
     }
     if (!any)
         return;
-    out->ops      = std::move(fused_ops);
-    out->segments = std::move(segs);
+    size_t m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!drop[(size_t)i])
+            ops[m++] = ops[(size_t)i];
+    ops.resize(m);
+    out->full = false;
+    out->fast = true;
+    for (const KOp& o : ops) {
+        if (refs_of(o) & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2)))
+            out->full = true;
+        if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
+            out->fast = false;
+    }
 }
 
 /* Per launch: which of its ops can touch which band of the frame. The kernels used to walk the whole op list in
@@ -1031,8 +1039,8 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
         if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
             out->fast = false;
     drop_hidden_ops(*fmt, out);
+    fuse_layers(*fmt, out);
     split_into_segments(*fmt, out);
-    fuse_layers(out);
     op_masks(*fmt, out);
     return CGHIP_OK;
 }

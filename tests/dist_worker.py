@@ -43,7 +43,7 @@ def main():
                 S.feed_product(mixers[c], scenes[c], via_factory=False)
                 draws, surfaces = mixers[c].flatten(W, H)
                 ops, _full = K.plan(A.Format(W, H, W, H, 8, 0), surfaces, draws)
-                assert len(draws) == 4 and len(ops) >= 3  # background, two MIX items, the composite of the mix texture
+                assert len(draws) == 4 and len(ops) >= 2  # background, two MIX items, the composite (one op with its item when a MIX weight is 0)
                 try:  # a dry-run mixer cannot render; the attempt ends the frame (the layer tree is consumed)
                     mixers[c].render(W, H)
                 except A.CGHIPError:

@@ -270,6 +270,16 @@ def test_fused_blend_layers_equal_the_three_draws(bits):
             finally:
                 L.cghip_debug_force_general_kernel(0)
             assert np.array_equal(fused, plain), (sc["name"], S.diff_stats(fused, plain))
+            if forced:  # and as the planner runs it: fused ops of the 4-pixels-per-lane kernels (blend body BB_FUSED)
+                fast_fused = S.run_product(sc, mixer=m, planes_cache=cache)
+                L.cghip_debug_no_layer_fusion(1)
+                try:
+                    fast_plain = S.run_product(sc, mixer=m, planes_cache=cache)
+                finally:
+                    L.cghip_debug_no_layer_fusion(0)
+                sd = S.diff_stats(fast_fused, fast_plain)
+                # 16-bit frames: the fused body takes the general fore-colour variant, fused multiply-adds differ
+                assert sd["max"] == 0 if bits == 8 else (sd["gt2"] <= 1e-3 and sd["gt0"] <= 2e-2), (sc["name"], sd)
             n_fused += any(o[0] == "push" and o[1].get("blend_mode", "normal") != "normal" for o in sc["ops"])
     finally:
         m.close()

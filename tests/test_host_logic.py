@@ -337,7 +337,7 @@ def check_segments(ops, segs, W, H):
             reads = [o.dst, o.local_key, o.layer_key] + ([o.src_surface] if o.kind == K.KOP_DRAW_SURFACE else [])
             if o.fused:  # a blend-mode layer with one item as ONE op: the composite's keys are read too
                 reads += [o.b_local_key, o.b_layer_key]
-                assert not sg["fast"] and o.kind == K.KOP_DRAW_PLANES and o.dst not in (1, 2)
+                assert o.kind == K.KOP_DRAW_PLANES and (not sg["fast"] or o.blend_body == 6)  # BB_FUSED
                 assert o.x0 <= o.ax0 and o.ax1 <= o.x1 and o.y0 <= o.ay0 and o.ay1 <= o.y1
             for s in reads:
                 if s >= 0:
@@ -425,9 +425,15 @@ def test_blend_mode_layers_with_one_item_are_fused_in_general_launches():
         assert len(ops3) == 20 and segs3[0]["full"] and not any(o.fused for o in ops3)
     finally:
         A.lib().cghip_debug_no_layer_fusion(0)
-    # a MIX pair shares its texture between two items: not fused; the fast kernels keep their own composite body
+    # a MIX pair shares its texture between two items: not fused
     ops4, segs4 = plan_with_segments(S.config4())
     assert not any(o.fused for o in ops4) and segs4[0]["fast"] and segs4[0]["full"]
+    # unit-scale items in blend-mode layers: fused ops of the 4-pixels-per-lane kernel WITHOUT the temporaries
+    sc = S.scene("blend_stack", 256, 64, [S.layer(S.bgra(256, 64, "premul", 70 + i), opacity=0.8, blend_mode=m)
+                                          for i, m in enumerate(["normal", "screen", "multiply", "overlay"])])
+    ops5, segs5 = plan_with_segments(sc)
+    assert len(ops5) == 4 and sum(o.fused for o in ops5) == 3 and segs5[0]["fast"] and not segs5[0]["full"]
+    assert all(o.blend_body == 6 for o in ops5 if o.fused)
 
 
 def test_empty_scene_is_one_launch_that_stores_the_frame():
