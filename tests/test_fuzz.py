@@ -38,6 +38,29 @@ def test_oracle_matches_llvmpipe_on_random_scenes(seed):
     assert st["gt0"] <= 2e-3 and st["gt1"] <= 6e-4, st
 
 
+def test_oracle_matches_llvmpipe_on_box_scenes():
+    """The same pin for the scenes of tests/fuzz_scenes.py: fuzz_box_scene (picture-in-picture boxes of sources of
+    their own size, 1:1 layers off the 4-pixel grid, boxes in blend-mode layers): the class the 4-pixels-per-lane
+    kernels sample themselves and that the GPU test compares with this oracle bit for bit."""
+    if not _gl():
+        pytest.skip("llvmpipe harness not available here")
+    from fuzz_scenes import fuzz_box_scene
+    worst = {"gt0": 0.0, "gt1": 0.0}
+    for seed in range(60):
+        sc = fuzz_box_scene(seed, 8, seed % 2 == 1)
+        cache = {}
+        a = S.run_oracle(sc, "cpu", cache)
+        b = S.run_oracle(sc, "gl", cache)
+        if sc["field_mode"]:
+            first = sc["field_mode"] - 1
+            assert not a[1 - first::2].any()
+            a, b = a[first::2], b[first::2]
+        st = S.diff_stats(a, b)
+        assert st["gt0"] <= 2e-3 and st["gt1"] <= 6e-4, (seed, st)  # same bound and reasons as above
+        worst = {k: max(worst[k], st[k]) for k in worst}
+    print("oracle vs llvmpipe on 60 box scenes, worst:", worst)
+
+
 def _gl_field(sc, a, b):
     if sc["field_mode"]:  # the field mask is this project's extension: GL draws every row
         first = sc["field_mode"] - 1
