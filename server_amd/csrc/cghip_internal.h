@@ -118,6 +118,7 @@ struct segment {
     bool     fast = false;         /* cghip_composite_fast, else cghip_composite */
     bool     full = false;         /* touches RGBA1 / RGBA2 */
     bool     fused = false;        /* holds a KOp::fused op */
+    bool     one_temp = false;     /* full, but RGBA2 is never touched, loaded or stored */
     int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
     int      gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0; /* pixel box the launch covers */

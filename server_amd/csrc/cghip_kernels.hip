@@ -1960,7 +1960,10 @@ DEV void fetch_rect16(const KOp& op, const HotG& g, int ax0, int ax1, int px0, i
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
-template <int BITS, bool FULL, int EXT> /* EXT: 0 aligned bodies only, 1 + sampled boxes, 2 + fused blend-mode layers */
+template <int BITS, bool FULL, int EXT, bool ONE = false> /* EXT: 0 aligned bodies only, 1 + sampled boxes, 2 + fused
+                                                            blend-mode layers. ONE (with FULL): the launch never touches
+                                                            RGBA2 - a MIX transition outside blend-mode layers - and
+                                                            the kernel does not hold it: 16 registers less per lane */
 DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, const KSpill& sp)
 {
     constexpr int  P       = 4;
@@ -1990,7 +1993,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 const size_t idx = (size_t)y * W + px0 + i;
                 if (sp.load_mask & (1u << KS_RGBA0)) S[i] = load_px<BITS>(out, idx);
                 if (FULL && (sp.load_mask & (1u << KS_RGBA1))) S1[i] = load_px<BITS>(sp.rgba1, idx);
-                if (FULL && (sp.load_mask & (1u << KS_RGBA2))) S2[i] = load_px<BITS>(sp.rgba2, idx);
+                if (FULL && !ONE && (sp.load_mask & (1u << KS_RGBA2))) S2[i] = load_px<BITS>(sp.rgba2, idx);
                 if (sp.load_mask & (1u << KS_KEY0)) K0[i] = load_key<BITS>(sp.key0, idx);
                 if (sp.load_mask & (1u << KS_KEY1)) K1[i] = load_key<BITS>(sp.key1, idx);
             }
@@ -2015,7 +2018,8 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 K1[i] = clr1 ? 0.0f : K1[i];
                 if (FULL) {
                     S1[i] = sel4(h.dst == KS_RGBA1, f4{0, 0, 0, 0}, S1[i]);
-                    S2[i] = sel4(h.dst == KS_RGBA2, f4{0, 0, 0, 0}, S2[i]);
+                    if constexpr (!ONE)
+                        S2[i] = sel4(h.dst == KS_RGBA2, f4{0, 0, 0, 0}, S2[i]);
                 }
             });
         }
@@ -2043,8 +2047,12 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
         switch (h.fetch_body) {
             case FB_SURFACE:
                 if constexpr (FULL) {
-                    const bool from2 = op.src_surface == KS_RGBA2;
-                    static_for<0, P>([&](auto I) { col[decltype(I)::value] = sel4(from2, S2[decltype(I)::value], S1[decltype(I)::value]); });
+                    if constexpr (ONE) {
+                        static_for<0, P>([&](auto I) { col[decltype(I)::value] = S1[decltype(I)::value]; });
+                    } else {
+                        const bool from2 = op.src_surface == KS_RGBA2;
+                        static_for<0, P>([&](auto I) { col[decltype(I)::value] = sel4(from2, S2[decltype(I)::value], S1[decltype(I)::value]); });
+                    }
                 } else {
                     static_for<0, P>([&](auto I) { col[decltype(I)::value] = f4{0, 0, 0, 0}; }); /* never planned */
                 }
@@ -2183,7 +2191,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 fore_key4<false>(h, col, K0, fo), store_key4<BITS>(fo, h.dst == KS_KEY1, K0, K1);
             } else if (h.dst == KS_RGBA0)
                 blend_into(S);
-            else if (h.dst == KS_RGBA1)
+            else if (ONE || h.dst == KS_RGBA1)
                 blend_into(S1);
             else
                 blend_into(S2);
@@ -2198,7 +2206,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
             if (px0 + i < W) {
                 const size_t idx = (size_t)y * W + px0 + i;
                 if (FULL && (sp.store_mask & (1u << KS_RGBA1))) store_px<BITS>(sp.rgba1, idx, S1[i]);
-                if (FULL && (sp.store_mask & (1u << KS_RGBA2))) store_px<BITS>(sp.rgba2, idx, S2[i]);
+                if (FULL && !ONE && (sp.store_mask & (1u << KS_RGBA2))) store_px<BITS>(sp.rgba2, idx, S2[i]);
                 if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0, idx, K0[i]);
                 if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1, idx, K1[i]);
             }
@@ -2260,6 +2268,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
 {
     composite_fast_body<BITS, true, 0>(ops, nops, out, W, H, field_mode, sp);
+}
+/* One temporary only (KSpill::one_temp: no op of the launch touches RGBA2): MIX transitions between unit-scale sources
+ * outside blend-mode layers, BASELINE config 4. */
+#ifndef ONE_TEMP_WAVES
+#define ONE_TEMP_WAVES 4
+#endif
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONE_TEMP_WAVES))) void cghip_composite_fast_one(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, true, 0, true>(ops, nops, out, W, H, field_mode, sp);
 }
 /* The same two with the sampled fetch bodies (FB_RECT8) compiled in, for launches that hold such a draw.
  * Kernels of their own: with those bodies in it the kernel of full-screen stacks allocated its registers differently
@@ -2386,6 +2405,8 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
             hipLaunchKernelGGL((cghip_composite_fast_x<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!full && !sampled)
             hipLaunchKernelGGL((cghip_composite_fast<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+        else if (!sampled && s.one_temp)
+            hipLaunchKernelGGL((cghip_composite_fast_one<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!sampled)
             hipLaunchKernelGGL((cghip_composite_fast_full<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!full)

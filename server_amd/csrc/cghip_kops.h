@@ -110,6 +110,7 @@ struct KSpill {
     const uint64_t* masks;
     int32_t  ncols, nrows, nchunks, col_shift;
     int32_t  dense; /* every op is in every band (full-screen stacks): the table is not read */
+    int32_t  one_temp; /* touches RGBA1 but not RGBA2 (loads and stores included): the fast kernel with one temporary */
     int32_t  fused; /* the launch holds a fused blend-mode layer (KOp::fused): picks the general kernel's instance */
 };
 

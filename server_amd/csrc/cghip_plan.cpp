@@ -747,6 +747,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         sg.store_mask = written & ~zero & later;
         if (si == 0)
             sg.store_mask |= surf_bit(KS_RGBA0); /* the first launch defines every pixel of the frame */
+        sg.one_temp = sg.full && !((touched | sg.load_mask | sg.store_mask) & surf_bit(KS_RGBA2));
         in_mem = (in_mem & ~written) | sg.store_mask;
         out->spill_mask |= (sg.load_mask | sg.store_mask) & ~surf_bit(KS_RGBA0);
 
