@@ -319,7 +319,7 @@ def main():
                 "channels_per_gpu": ncha, "frames_in_flight": 2, "settle_s": args.settle, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": {"config4": "cghip_composite_fast_full<%d>", "config2": "cghip_composite<%d>"}.get(
+                         "kernel": {"config4": "cghip_composite_fast_one<%d>", "config2": "cghip_composite<%d, false, true>"}.get(
                              args.workload, "cghip_composite_fast<%d>") % scene["bits"],
                          "avg_kernel_ms": avg_kernel_ms, "launch_ms": launch_stats,
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
