@@ -436,6 +436,28 @@ def test_blend_mode_layers_with_one_item_are_fused_in_general_launches():
     assert all(o.blend_body == 6 for o in ops5 if o.fused)
 
 
+def test_nested_blend_sublayer_with_a_mix_pair_fits_two_temporaries():
+    """The kernels hold the target, two RGBA temporaries and two key surfaces in registers (INTEGRATION.md section 4
+    documents the limit and the CGHIP_ERR_UNSUPPORTED a frame beyond it gets). The deepest nesting the reference's own
+    renderer produces for RGBA temporaries - a MIX pair inside a blend-mode sublayer inside a blend-mode layer, then a
+    plain item - never has more than two alive: the planner binds four surface slots to the two registers, and the
+    oracle issues the same seven draws."""
+    W, H = 64, 32
+    inner = [("push", dict(layer_depth=1, blend_mode="multiply")),
+             ("push", dict(is_mix=1, opacity=0.4)), ("visit", S.bgra(W, H, "premul", 81)), ("pop",),
+             ("push", dict(is_mix=1, opacity=0.6)), ("visit", S.bgra(W, H, "premul", 82)), ("pop",),
+             ("pop",)]
+    nested = S.scene("nested_blend_mix", W, H,
+                     [S.layer(S.bgra(W, H, "premul", 80)),
+                      [("push", dict(layer_depth=1, blend_mode="screen"))] + inner +
+                      [("push", dict(opacity=0.5)), ("visit", S.bgra(W, H, "premul", 83)), ("pop",), ("pop",)]])
+    assert _draw_sequence(nested) == [("P", 0, -1), ("M", 2, -1), ("M", 2, -1), ("S", 1, 2), ("S", 0, 1), ("P", 3, -1),
+                                      ("S", 0, 3)]
+    _d, surfaces, ops, full = product_plan(nested)
+    assert len(surfaces) == 4 and full and {o.dst for o in ops} == {0, 1, 2}
+    assert len(oracle_log(nested)) == 7
+
+
 def test_empty_scene_is_one_launch_that_stores_the_frame():
     fmt = A.Format(64, 64, 64, 64, 8, 0)
     segs = K.plan_segments(fmt, [4], [])
