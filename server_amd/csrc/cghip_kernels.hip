@@ -789,43 +789,39 @@ DEV int lerp8s(int a, int b, int w)
 /* byte offsets of the four taps of a GL_LINEAR + CLAMP_TO_EDGE fetch at 24.8 fixed-point texel coordinates
  * (already shifted by half a texel), and the two 8-bit weights */
 struct Taps {
-    uint32_t o00, o01, o10, o11;
+    uint32_t o0, o1; /* byte offsets of the tap PAIR (columns x, x + 1) in row y0 and in row y1 */
     int      wx, wy;
 };
+/* The two column taps of a row are neighbours in memory, so one load of two texels serves both (planes of this class
+ * are at least two texels wide, cghip_plan.cpp: classify_sampling). CLAMP_TO_EDGE: left of the plane both taps are
+ * texel 0 - weight 0 on the pair (0, 1); right of column w - 2 both are texel w - 1 - weight 256 on the pair
+ * (w - 2, w - 1): lerp8 with weight 256 returns its second operand exactly. Twelve loads per pixel of a planar source
+ * became six. */
 DEV Taps make_taps(int iu, int iv, int w, int h, uint32_t texel_bytes)
 {
-    int       x0 = iu >> 8, y0 = iv >> 8;
-    const int x1 = iclamp(x0 + 1, 0, w - 1), y1 = iclamp(y0 + 1, 0, h - 1);
-    x0           = iclamp(x0, 0, w - 1);
+    const int x0 = iu >> 8;
+    int       y0 = iv >> 8, wx = iu & 0xff;
+    wx           = x0 < 0 ? 0 : wx;
+    wx           = x0 > w - 2 ? 256 : wx;
+    const int xp = iclamp(x0, 0, w - 2), y1 = iclamp(y0 + 1, 0, h - 1);
     y0           = iclamp(y0, 0, h - 1);
     const uint32_t r0 = (uint32_t)y0 * (uint32_t)w, r1 = (uint32_t)y1 * (uint32_t)w;
-#ifdef CGHIP_X_ONE_TAP /* measurement only (profiles/r02_tap_experiment.txt): all four taps read the first tap's texel */
-    const uint32_t o = (r0 + (uint32_t)x0) * texel_bytes;
-    return Taps{o, o + 0u * (uint32_t)x1, o + 0u * r1, o, iu & 0xff, iv & 0xff};
-#endif
-    return Taps{(r0 + (uint32_t)x0) * texel_bytes, (r0 + (uint32_t)x1) * texel_bytes, (r1 + (uint32_t)x0) * texel_bytes,
-                (r1 + (uint32_t)x1) * texel_bytes, iu & 0xff, iv & 0xff};
+    return Taps{(r0 + (uint32_t)xp) * texel_bytes, (r1 + (uint32_t)xp) * texel_bytes, wx, iv & 0xff};
 }
 /* 1-channel plane: the filtered code 0..255 (x first, then y, 8-bit intermediates: sample8_fixed for one byte;
  * a zero weight leaves the first operand untouched, so no tap is conditional) */
 DEV float tap1(uint64_t ptr, const Taps t)
 {
     const GB  b   = (GB)ptr;
-#ifdef CGHIP_X_ONE_LOAD /* measurement only: ONE load per plane, its value stands in for the other three taps */
-    const int a00 = load_at<uint8_t>(b, t.o00), a01 = a00 ^ (int)(t.o01 & 1u), a10 = a00 ^ (int)(t.o10 & 2u), a11 = a00 ^ (int)(t.o11 & 3u);
-#else
-    const int a00 = load_at<uint8_t>(b, t.o00), a01 = load_at<uint8_t>(b, t.o01);
-    const int a10 = load_at<uint8_t>(b, t.o10), a11 = load_at<uint8_t>(b, t.o11);
-#endif
-    return (float)lerp8s(lerp8s(a00, a01, t.wx), lerp8s(a10, a11, t.wx), t.wy);
+    const int top = load_at<uint16_t>(b, t.o0), bot = load_at<uint16_t>(b, t.o1);
+    return (float)lerp8s(lerp8s(top & 0xff, top >> 8, t.wx), lerp8s(bot & 0xff, bot >> 8, t.wx), t.wy);
 }
 /* 4-channel plane: the four filtered bytes, memory order */
 DEV uint32_t tap4(uint64_t ptr, const Taps t)
 {
-    const GB       b   = (GB)ptr;
-    const uint32_t a00 = load_at<uint32_t>(b, t.o00), a01 = load_at<uint32_t>(b, t.o01);
-    const uint32_t a10 = load_at<uint32_t>(b, t.o10), a11 = load_at<uint32_t>(b, t.o11);
-    return lerp8x4(lerp8x4(a00, a01, (uint32_t)t.wx), lerp8x4(a10, a11, (uint32_t)t.wx), (uint32_t)t.wy);
+    const GB    b   = (GB)ptr;
+    const u32x2 top = load_at<u32x2>(b, t.o0), bot = load_at<u32x2>(b, t.o1);
+    return lerp8x4(lerp8x4(top.x, top.y, (uint32_t)t.wx), lerp8x4(bot.x, bot.y, (uint32_t)t.wx), (uint32_t)t.wy);
 }
 
 /* op fields of the general kernel, fetched in one scalar batch at the top of the op loop (see HotOp) */
@@ -913,12 +909,30 @@ DEV float bilerp_f(float a00, float a01, float a10, float a11, float wx, float w
     const float a = a00 + wx * (a01 - a00), c = a10 + wx * (a11 - a10);
     return a + wy * (c - a);
 }
-DEV float tap1_16(uint64_t ptr, const TapsF t)
+/* 1-channel 16-bit plane: tap pairs again (see make_taps); at the plane's edges, where CLAMP_TO_EDGE makes both taps
+ * the same texel, a byte permute overwrites the pair's other half with it (a + w * (b - a) with b == a is a) */
+struct TapsP {
+    uint32_t o0, o1, sel;
+    float    wx, wy;
+};
+DEV TapsP make_taps_p(float u, float v, int w, int h)
 {
-    const GB    b  = (GB)ptr;
-    const float sc = 1.0f / 65535.0f;
-    return bilerp_f((float)load_at<uint16_t>(b, t.o00) * sc, (float)load_at<uint16_t>(b, t.o01) * sc,
-                    (float)load_at<uint16_t>(b, t.o10) * sc, (float)load_at<uint16_t>(b, t.o11) * sc, t.wx, t.wy);
+    const float fx = __builtin_floorf(u), fy = __builtin_floorf(v);
+    const int   x0 = (int)fx;
+    int         y0 = (int)fy;
+    const int   y1 = iclamp(y0 + 1, 0, h - 1);
+    y0             = iclamp(y0, 0, h - 1);
+    const uint32_t xp = (uint32_t)iclamp(x0, 0, w - 2);
+    const uint32_t sel = x0 < 0 ? 0x01000100u : (x0 > w - 2 ? 0x03020302u : 0x03020100u);
+    return TapsP{((uint32_t)y0 * (uint32_t)w + xp) * 2u, ((uint32_t)y1 * (uint32_t)w + xp) * 2u, sel, u - fx, v - fy};
+}
+DEV float tap1_16(uint64_t ptr, const TapsP t)
+{
+    const GB       b  = (GB)ptr;
+    const float    sc = 1.0f / 65535.0f;
+    const uint32_t top = load_at<uint32_t>(b, t.o0), bot = load_at<uint32_t>(b, t.o1);
+    const uint32_t tp = __builtin_amdgcn_perm(top, top, t.sel), bp = __builtin_amdgcn_perm(bot, bot, t.sel);
+    return bilerp_f((float)(tp & 0xffff) * sc, (float)(tp >> 16) * sc, (float)(bp & 0xffff) * sc, (float)(bp >> 16) * sc, t.wx, t.wy);
 }
 template <bool UNIT>
 DEV f4 source_color_class16(const KOp& op, const HotG& h, float s, float t, int px, int py)
@@ -941,8 +955,8 @@ DEV f4 source_color_class16(const KOp& op, const HotG& h, float s, float t, int 
 #undef CH
         return swizzle_format(h.pixel_format, f4{m2, m1, m0, m3}); /* gl_texel of a GL_BGRA upload */
     }
-    const TapsF t0 = make_taps_f(coord(s, h.fw0, h.fw0, px), coord(t, h.fh0, h.fh0, py), h.w0, h.h0, 2u);
-    const TapsF t1 = make_taps_f(coord(s, h.fw1, h.fw0, px), coord(t, h.fh1, h.fh0, py), h.w1, h.h1, 2u);
+    const TapsP t0 = make_taps_p(coord(s, h.fw0, h.fw0, px), coord(t, h.fh0, h.fh0, py), h.w0, h.h0);
+    const TapsP t1 = make_taps_p(coord(s, h.fw1, h.fw0, px), coord(t, h.fh1, h.fh0, py), h.w1, h.h1);
     const float Y = tap1_16(h.ptr0, t0), Cb = tap1_16(h.ptr1, t1), Cr = tap1_16(h.ptr2, t1);
     float       A = 1.0f;
     if (h.pixel_format == 6)

@@ -331,6 +331,10 @@ static void classify_sampling(KOp& op)
     if (p0.bits != 8 && p0.bits != 16)
         return;
     const bool wide = p0.bits == 16;
+    if (!wide) /* the 8-bit bodies fetch both column taps of a row with one two-texel load */
+        for (int n = 0; n < op.nplanes; ++n)
+            if (op.planes[n].w < 2)
+                return;
     if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
         op.sample_class = wide ? SC_PACKED16 : SC_PACKED8;
         return;
@@ -343,6 +347,10 @@ static void classify_sampling(KOp& op)
             return;
         if (pf == 6 && (op.planes[3].w != p0.w || op.planes[3].h != p0.h))
             return;
+        if (wide) /* 16-bit planar bodies fetch tap pairs too (packed 16-bit ones do not) */
+            for (int n = 0; n < op.nplanes; ++n)
+                if (op.planes[n].w < 2)
+                    return;
         op.sample_class = wide ? SC_PLANAR16 : SC_PLANAR8;
     }
 }
