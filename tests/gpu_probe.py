@@ -11,8 +11,11 @@ from bench import Channel, run_steps
 W, H = int(os.environ.get("PROBE_W", "3840")), int(os.environ.get("PROBE_H", "2160"))
 NL = int(os.environ.get("PROBE_LAYERS", "8"))
 SUB = os.environ.get("PROBE_SUB", "422")
+BLEND_MODE = os.environ.get("PROBE_BLEND", "screen")
+
+
 def stack(kind, bits):
-    t = {"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
+    t = {"mix_blend": {},"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
          "levels": dict(opacity=0.7, **S.LEVELS), "bgra": dict(opacity=0.8),
          # general-kernel paths: scaled (axis-aligned), rotated, perspective, unit-scale with a blend mode
          "g_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]), "g_rot": dict(opacity=0.8, angle=0.05),
@@ -25,6 +28,12 @@ def stack(kind, bits):
     ops = []
     for i in range(NL):
         spec = S.bgra(W, H, "premul", 500 + i, bits=bits) if "bgra" in kind else S.ycbcr(W, H, SUB, "video", 500 + i, bits=bits)
+        if kind == "mix_blend":  # a MIX pair inside a blend-mode layer: the kernels with TWO RGBA temporaries
+            other = S.bgra(W, H, "premul", 700 + i, bits=bits)
+            ops.append([("push", dict(layer_depth=1, blend_mode=BLEND_MODE, opacity=0.8)),
+                        ("push", dict(is_mix=1, opacity=0.6)), ("visit", spec), ("pop",),
+                        ("push", dict(is_mix=1, opacity=0.4)), ("visit", other), ("pop",), ("pop",)])
+            continue
         ops.append(S.layer(spec, **t))
     return S.scene("%s_%d" % (kind, bits), W, H, ops, bits=bits)
 
