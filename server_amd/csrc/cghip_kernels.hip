@@ -1479,6 +1479,37 @@ DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
     }
 }
 
+/* source colours of four pixels from an 8-bit uyvy frame at unit scale (pixel format 10: what SDI capture delivers,
+ * modules/ffmpeg/util/av_util.cpp:163-171). The frame is ONE buffer of U Y0 V Y1 groups bound twice: as an RG8 plane
+ * w x h, whose .g is luma at the pixel's own texel, and as an RGBA8 plane (w/2) x h, whose .b / .r are Cb / Cr, filtered
+ * across the half-width texels with the exact 1/4 - 3/4 weights like a 4:2:2 chroma plane (shader.frag:513-519). A
+ * lane's four pixels are two such groups: one 8-byte load, plus the group to the left and to the right (clamped). */
+DEV void fetch_uyvy8(const HotOp& op, int sx, int sy, f4 col[4])
+{
+    const GB       row = row_base(op.ptr1, sy, op.w1, 4u); /* scalar */
+    const int      k   = sx >> 1;                          /* first of the lane's two groups */
+    const u32x2    g   = load_at<u32x2>(row, (uint32_t)k * 4u);
+    const uint32_t gl  = load_at<uint32_t>(row, (uint32_t)imax(k - 1, 0) * 4u);
+    const uint32_t gr  = load_at<uint32_t>(row, (uint32_t)imin(k + 2, op.w1 - 1) * 4u);
+    const float    sc  = 1.0f / 255.0f;
+    float          Y[4] = {(float)((g.x >> 8) & 0xff), (float)(g.x >> 24), (float)((g.y >> 8) & 0xff), (float)(g.y >> 24)};
+    float          Cb[4], Cr[4];
+    convert_row<8, 1>(Row3{(g.x & 0xff) | ((g.y & 0xff) << 8), gl & 0xff, gr & 0xff}, Cb);
+    convert_row<8, 1>(Row3{((g.x >> 16) & 0xff) | (((g.y >> 16) & 0xff) << 8), (gl >> 16) & 0xff, (gr >> 16) & 0xff}, Cr);
+    const bool  hd  = op.flags & KF_IS_HD;
+    const float krr = hd ? 1.793f : 1.596f, kgr = hd ? 0.534f : 0.813f, kgb = hd ? 0.213f : 0.391f,
+                kbb = hd ? 2.115f : 2.018f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { /* ycbcra_to_rgba(), as in fetch_planar */
+        const float yy = 1.164f * ((Y[i] * sc) * 255.0f - 16.0f);
+        const float cr = (Cr[i] * sc) * 255.0f - 128.0f, cb = (Cb[i] * sc) * 255.0f - 128.0f;
+        col[i].z = divc<RXF>((yy + krr * cr), 255.0f, 1.0f / 255.0f);
+        col[i].y = divc<RXF>((yy - kgr * cr - kgb * cb), 255.0f, 1.0f / 255.0f);
+        col[i].x = divc<RXF>((yy + kbb * cb), 255.0f, 1.0f / 255.0f);
+        col[i].w = 1.0f;
+    }
+}
+
 /* ---- the same for 16-bit planes in 16-bit frames (relaxed numerics, see divf) ----
  * Between the sample codes and the colour there is nothing but affine maps: code / 65535, the 1/4 - 3/4 lerps of the
  * half-resolution chroma planes, Y' = 1.164 (255 Y - 16), the matrix, / 255 (shader.frag:441-467). Composed:
@@ -2105,6 +2136,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 if constexpr (SAMPLED)
                     fetch_rect16<true, true>(op, load_hot_g<false>(op), h.ax0, h.ax1, opaque_v(px0), opaque_s(y), col, cover);
                 break;
+            case FB_UYVY8: fetch_uyvy8(h, sx, SY, col); break;
             case FB_PACKED8: fetch_packed<8>(h, sx, SY, col); break;
             case FB_PACKED16: fetch_packed<16>(h, sx, SY, col); break;
             case FB_PLANAR8 + 0: fetch_planar<8, 0, 0>(h, sx, SY, red_only, col); break;

@@ -42,6 +42,7 @@ enum KFastClass : int32_t {
     FC_PACKED = 1, /* one 4-channel plane (bgra / rgba / argb / abgr), unit scale */
     FC_PLANAR = 2, /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
     FC_SURFACE = 3, /* KOP_DRAW_SURFACE: a layer / mix temporary composited 1:1 (any blend mode, either keyer) */
+    FC_UYVY    = 5, /* 8-bit uyvy at unit scale: one buffer bound as RG8 w x h and RGBA8 (w/2) x h */
     FC_SAMPLED = 4  /* planes in one of the straight-line sampling layouts (KSampleClass), axis-aligned box at
                        any scale or 1:1 off the 4-texel grid: four bilinear fetches per lane, coverage per pixel */
 };
@@ -54,6 +55,7 @@ enum KFetchBody : int32_t {
     FB_PACKED16 = 2,
     FB_PLANAR8  = 3, /* + csx + 2 * csy */
     FB_PLANAR16 = 7, /* + csx + 2 * csy */
+    FB_UYVY8    = 11, /* FC_UYVY */
     FB_RECT16   = 16, /* the same four for 16-bit planes (fp32 filter weights) */
     FB_RECT8    = 12  /* FC_SAMPLED with KF_AXIS or KF_UNIT_SCALE and 8-bit planes: + 0 ycbcr(a) planes, + 1 one packed
                          plane, + 2 if KF_UNIT_SCALE (a 1:1 source off the aligned bodies' 4-texel grid) */

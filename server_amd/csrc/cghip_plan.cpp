@@ -212,6 +212,7 @@ static void classify_fast(KOp& op, int frame_w)
     /* the bodies of cghip_composite_fast that run this draw */
     const bool wide = op.planes[0].bits == 16;
     op.fetch_body   = op.fast_class == FC_SURFACE   ? (int)FB_SURFACE
+                      : op.fast_class == FC_UYVY    ? (int)FB_UYVY8
                       : op.fast_class == FC_SAMPLED ? (wide ? (int)FB_RECT16 : (int)FB_RECT8) + (op.sample_class == SC_PACKED8 || op.sample_class == SC_PACKED16 ? 1 : 0) +
                                             ((op.flags & KF_UNIT_SCALE) ? 2 : 0)
                       : op.fast_class == FC_PACKED  ? (wide ? (int)FB_PACKED16 : (int)FB_PACKED8)
@@ -276,6 +277,13 @@ static void classify_fast_draw(KOp& op, int frame_w)
     const int pf = op.pixel_format;
     if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
         op.fast_class = FC_PACKED;
+        return;
+    }
+    if (pf == 10 && op.nplanes == 2) { /* uyvy: both planes are views of one buffer (av_util.cpp:163-171) */
+        const KPlane& p1 = op.planes[1];
+        if (p0.bits == 8 && p1.bits == 8 && p0.channels == 2 && p1.channels == 4 && p1.w * 2 == p0.w && p1.h == p0.h &&
+            p1.w >= 2 && (const char*)p1.ptr == (const char*)p0.ptr)
+            op.fast_class = FC_UYVY;
         return;
     }
     if ((pf == 5 && op.nplanes == 3) || (pf == 6 && op.nplanes == 4)) {

@@ -115,9 +115,11 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     s = 9000 + 131 * seed
     for i in range(rng.randint(1, 7)):
         f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420",
-                        "solid"])
+                        "solid"] + (["uyvy"] if bits == 8 else []))  # uyvy: what SDI capture delivers (8-bit only)
         kind = rng.choice(["smooth", "noise", "video"])
-        if f == "solid":  # the colour producer: one 1x1 texel stretched over a rectangle on 4-pixel columns
+        if f == "uyvy":
+            src = S.frame("uyvy", [(W, H, 2, kind, s + i)], bits)
+        elif f == "solid":  # the colour producer: one 1x1 texel stretched over a rectangle on 4-pixel columns
             src = S.frame(rng.choice(["bgra", "rgba", "argb", "abgr"]), [(1, 1, 4, "noise", s + i)], bits)
         elif f in ("bgra", "rgba", "argb", "abgr"):
             src = S.frame(f, [(W, H, 4, rng.choice(["premul", "noise", "smooth"]), s + i)], bits)
