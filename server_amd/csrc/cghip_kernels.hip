@@ -868,7 +868,18 @@ DEV f4 source_color_class(const KOp& op, const HotG& h, float s, float t, int px
         return (int)__builtin_rintf(v * size * 256.0f) - 128;
     };
     const Taps t0 = make_taps(coord(s, h.fw0, h.fw0, px), coord(t, h.fh0, h.fh0, py), h.w0, h.h0,
-                              h.sample_class == SC_PACKED8 ? 4u : 1u);
+                              h.sample_class == SC_PACKED8 ? 4u : h.sample_class == SC_UYVY8 ? 2u : 1u);
+    if (h.sample_class == SC_UYVY8) { /* shader.frag:513-519: Y = plane0.g, Cb = plane1.b, Cr = plane1.r */
+        const Taps     t1 = make_taps(coord(s, h.fw1, h.fw0, px), coord(t, h.fh1, h.fh0, py), h.w1, h.h1, 4u);
+        const uint32_t yt = load_at<uint32_t>((GB)h.ptr0, t0.o0), yb = load_at<uint32_t>((GB)h.ptr0, t0.o1);
+        const u32x2    ct = load_at<u32x2>((GB)h.ptr1, t1.o0), cb = load_at<u32x2>((GB)h.ptr1, t1.o1);
+        const float    sc = 1.0f / 255.0f;
+        const float    Y  = (float)lerp8s(lerp8s((yt >> 8) & 0xff, yt >> 24, t0.wx), lerp8s((yb >> 8) & 0xff, yb >> 24, t0.wx), t0.wy);
+        const float    U  = (float)lerp8s(lerp8s(ct.x & 0xff, ct.y & 0xff, t1.wx), lerp8s(cb.x & 0xff, cb.y & 0xff, t1.wx), t1.wy);
+        const float    V  = (float)lerp8s(lerp8s((ct.x >> 16) & 0xff, (ct.y >> 16) & 0xff, t1.wx),
+                                          lerp8s((cb.x >> 16) & 0xff, (cb.y >> 16) & 0xff, t1.wx), t1.wy);
+        return ycbcra_to_rgba(Y * sc, U * sc, V * sc, 1.0f, h.flags & KF_IS_HD);
+    }
     if (h.sample_class == SC_PACKED8) {
         const int      pf  = h.pixel_format;
         const uint32_t sel = pf == 1 ? 0x03020100u : pf == 2 ? 0x03000102u : pf == 3 ? 0x00010203u : 0x02030001u;
@@ -973,7 +984,7 @@ DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
        the exact texel keeps this kernel and cghip_composite_fast identical on the layers they share. */
     if (h.flags & KF_UNIT_SCALE) {
         const int px = x + h.unit_dx, py = y + h.unit_dy;
-        color = h.sample_class >= SC_PLANAR16  ? source_color_class16<true>(op, h, 0.0f, 0.0f, px, py)
+        color = ((h.sample_class == SC_PLANAR16) | (h.sample_class == SC_PACKED16)) ? source_color_class16<true>(op, h, 0.0f, 0.0f, px, py)
                 : h.sample_class != SC_GENERIC ? source_color_class<true>(op, h, 0.0f, 0.0f, px, py)
                                                : source_color_unit(op, px, py);
         return true;
@@ -1020,7 +1031,7 @@ DEV bool source_color(const KOp& op, const HotG& h, int x, int y, f4& color)
             t /= q0;
         }
     }
-    color = h.sample_class >= SC_PLANAR16  ? source_color_class16<false>(op, h, s, t, 0, 0)
+    color = ((h.sample_class == SC_PLANAR16) | (h.sample_class == SC_PACKED16)) ? source_color_class16<false>(op, h, s, t, 0, 0)
             : h.sample_class != SC_GENERIC ? source_color_class<false>(op, h, s, t, 0, 0)
                                            : source_color_norm(op, s, t);
     return true;
@@ -1889,6 +1900,47 @@ DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, in
     }
 }
 
+/* FB_RECT_UYVY8: a box of an 8-bit uyvy frame (a live SDI input in a picture-in-picture box): luma pairs from the RG8
+ * view, chroma pairs from the RGBA8 view of half the width; same structure and arithmetic as fetch_rect8 */
+template <bool UNIT>
+DEV void fetch_rect_uyvy8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, int y, f4 col[4], uint32_t& cover)
+{
+    const KTri& T  = op.tri[0];
+    auto coord = [](float v, float size256) -> int { return (int)__builtin_rintf(v * size256) - 128; };
+    const float  t   = UNIT ? (float)(y + g.unit_dy) + 0.5f : (float)__builtin_fma(T.a[1][2], (double)y, T.a[1][0]);
+    const float  sh0 = UNIT ? (g.fh0 / g.fh0) * 256.0f : g.fh0 * 256.0f, sh1 = UNIT ? (g.fh1 / g.fh0) * 256.0f : g.fh1 * 256.0f;
+    const float  sw0 = UNIT ? (g.fw0 / g.fw0) * 256.0f : g.fw0 * 256.0f, sw1 = UNIT ? (g.fw1 / g.fw0) * 256.0f : g.fw1 * 256.0f;
+    const int    iv0 = __builtin_amdgcn_readfirstlane(coord(t, sh0)), iv1 = __builtin_amdgcn_readfirstlane(coord(t, sh1));
+    const double a01 = T.a[0][1], a00 = T.a[0][0];
+    const float  sc  = 1.0f / 255.0f;
+    const RowTaps ry = row_taps(g.ptr0, iv0, g.w0, g.h0, 2u), rc = row_taps(g.ptr1, iv1, g.w1, g.h1, 4u);
+    const bool    hd = g.flags & KF_IS_HD;
+    ColTaps       c0[4], c1[4];
+    uint32_t      yt[4], yb[4];
+    u32x2         ct[4], cb[4];
+    static_for<0, 4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int     x = px0 + i;
+        const float   s = UNIT ? (float)(x + g.unit_dx) + 0.5f : (float)__builtin_fma(a01, (double)x, a00);
+        c0[i] = col_taps(coord(s, sw0), g.w0), c1[i] = col_taps(coord(s, sw1), g.w1);
+        cover |= ((x >= ax0) & (x < ax1)) ? 1u << i : 0u;
+    });
+    static_for<0, 4>([&](auto I) { /* all loads first */
+        constexpr int i = decltype(I)::value;
+        yt[i] = load_at<uint32_t>(ry.r0, c0[i].x * 2u), yb[i] = load_at<uint32_t>(ry.r1, c0[i].x * 2u);
+        ct[i] = load_at<u32x2>(rc.r0, c1[i].x * 4u), cb[i] = load_at<u32x2>(rc.r1, c1[i].x * 4u);
+    });
+    static_for<0, 4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int     wx0 = c0[i].wx, wx1 = c1[i].wx;
+        const float   Y = (float)lerp8s(lerp8s((yt[i] >> 8) & 0xff, yt[i] >> 24, wx0), lerp8s((yb[i] >> 8) & 0xff, yb[i] >> 24, wx0), ry.wy);
+        const float   U = (float)lerp8s(lerp8s(ct[i].x & 0xff, ct[i].y & 0xff, wx1), lerp8s(cb[i].x & 0xff, cb[i].y & 0xff, wx1), rc.wy);
+        const float   V = (float)lerp8s(lerp8s((ct[i].x >> 16) & 0xff, (ct[i].y >> 16) & 0xff, wx1),
+                                        lerp8s((cb[i].x >> 16) & 0xff, (cb[i].y >> 16) & 0xff, wx1), rc.wy);
+        col[i] = ycbcra_to_rgba(Y * sc, U * sc, V * sc, 1.0f, hd);
+    });
+}
+
 /* FB_RECT16: the same for 16-bit planes, filtered with fp32 weights like source_color_class16<false> (make_taps_f,
  * bilerp_f), term for term. The two column taps again arrive in one load; at the plane's edges, where CLAMP_TO_EDGE
  * makes both taps the same texel, the pair's other half is overwritten with it (a + w * (b - a) with b == a is a for any
@@ -2119,6 +2171,14 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
             case FB_RECT8 + 3:
                 if constexpr (SAMPLED)
                     fetch_rect8<true, true>(op, load_hot_g<false>(op), h.ax0, h.ax1, opaque_v(px0), opaque_s(y), col, cover);
+                break;
+            case FB_RECT_UYVY8 + 0:
+                if constexpr (SAMPLED)
+                    fetch_rect_uyvy8<false>(op, load_hot_g<false>(op), h.ax0, h.ax1, opaque_v(px0), opaque_s(y), col, cover);
+                break;
+            case FB_RECT_UYVY8 + 1:
+                if constexpr (SAMPLED)
+                    fetch_rect_uyvy8<true>(op, load_hot_g<false>(op), h.ax0, h.ax1, opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_RECT16 + 0:
                 if constexpr (SAMPLED)

@@ -57,6 +57,7 @@ enum KFetchBody : int32_t {
     FB_PLANAR16 = 7, /* + csx + 2 * csy */
     FB_UYVY8    = 11, /* FC_UYVY */
     FB_RECT16   = 16, /* the same four for 16-bit planes (fp32 filter weights) */
+    FB_RECT_UYVY8 = 20, /* and for 8-bit uyvy (SC_UYVY8): + 1 if KF_UNIT_SCALE */
     FB_RECT8    = 12  /* FC_SAMPLED with KF_AXIS or KF_UNIT_SCALE and 8-bit planes: + 0 ycbcr(a) planes, + 1 one packed
                          plane, + 2 if KF_UNIT_SCALE (a 1:1 source off the aligned bodies' 4-texel grid) */
 };
@@ -77,7 +78,8 @@ enum KSampleClass : int32_t {
     SC_PLANAR8  = 1, /* ycbcr / ycbcra, every plane 1 channel 8 bit, Cb and Cr of one size, alpha the size of Y */
     SC_PACKED8  = 2, /* bgra / rgba / argb / abgr in one 4-channel 8-bit plane */
     SC_PLANAR16 = 3, /* the same two layouts with 16-bit samples (fp32 filter weights) */
-    SC_PACKED16 = 4
+    SC_PACKED16 = 4,
+    SC_UYVY8    = 5  /* 8-bit uyvy: luma from the RG8 view (.g), Cb / Cr from the RGBA8 view of half the width (.b / .r) */
 };
 
 /* register-resident surfaces the kernel has names for */

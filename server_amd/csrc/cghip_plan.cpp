@@ -213,8 +213,11 @@ static void classify_fast(KOp& op, int frame_w)
     const bool wide = op.planes[0].bits == 16;
     op.fetch_body   = op.fast_class == FC_SURFACE   ? (int)FB_SURFACE
                       : op.fast_class == FC_UYVY    ? (int)FB_UYVY8
-                      : op.fast_class == FC_SAMPLED ? (wide ? (int)FB_RECT16 : (int)FB_RECT8) + (op.sample_class == SC_PACKED8 || op.sample_class == SC_PACKED16 ? 1 : 0) +
-                                            ((op.flags & KF_UNIT_SCALE) ? 2 : 0)
+                      : op.fast_class == FC_SAMPLED ? (op.sample_class == SC_UYVY8
+                                           ? (int)FB_RECT_UYVY8 + ((op.flags & KF_UNIT_SCALE) ? 1 : 0)
+                                           : (wide ? (int)FB_RECT16 : (int)FB_RECT8) +
+                                                 (op.sample_class == SC_PACKED8 || op.sample_class == SC_PACKED16 ? 1 : 0) +
+                                                 ((op.flags & KF_UNIT_SCALE) ? 2 : 0))
                       : op.fast_class == FC_PACKED  ? (wide ? (int)FB_PACKED16 : (int)FB_PACKED8)
                                                    : (wide ? (int)FB_PLANAR16 : (int)FB_PLANAR8) + op.csx + 2 * op.csy;
     const bool to_key = op.dst >= KS_KEY0;
@@ -345,6 +348,10 @@ static void classify_sampling(KOp& op)
                 return;
     if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
         op.sample_class = wide ? SC_PACKED16 : SC_PACKED8;
+        return;
+    }
+    if (pf == 10 && op.nplanes == 2 && !wide && p0.channels == 2 && op.planes[1].channels == 4 && op.planes[1].bits == 8) {
+        op.sample_class = SC_UYVY8; /* widths >= 2 checked above */
         return;
     }
     if ((pf == 5 && op.nplanes == 3) || (pf == 6 && op.nplanes == 4)) {
@@ -663,7 +670,8 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             if (k == 0)
                 return (o.kind == KOP_DRAW_SURFACE ? 4.4 : (planes && !(o.flags & KF_RECT)) ? 6.0 : 4.8) + fused;
             if (planes && o.fetch_body >= FB_RECT8)
-                return ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.15 : 1.0) + (temp ? 1.5 : 0.0) + fused;
+                return (o.fetch_body >= FB_RECT_UYVY8 ? 3.2 : ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.15 : 1.0)) +
+                       (temp ? 1.5 : 0.0) + fused;
             if (o.kind == KOP_DRAW_SURFACE)
                 return o.blend_mode != 0 ? 3.3 : 1.9;
             return (fmt.bits == 16 ? 1.6 : 1.9) + fused;

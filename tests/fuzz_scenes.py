@@ -185,14 +185,17 @@ def fuzz_box_scene(seed, bits=8, full=False):
     ops = []
     s = 12000 + 137 * seed
     for i in range(rng.randint(2, 6)):
-        f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420"])
+        f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420"] +
+                       (["uyvy", "uyvy"] if bits == 8 else []))  # a live SDI input in a box
         mode = rng.choice(["box", "box", "box", "shift", "plain"])
         if mode == "box":  # a source of its own size; 4:2:x needs even sizes, chroma planes stay >= 2 texels wide
             sw, sh = rng.choice([(W, H), (W // 2, H // 2), (2 * W, 2 * H), (40, 30), (6, 4), (4, 2), (130, 70)])
         else:
             sw, sh = W, H
         kind = rng.choice(["smooth", "noise", "video"])
-        if f in ("bgra", "rgba", "argb", "abgr"):
+        if f == "uyvy":
+            src = S.frame("uyvy", [(sw, sh, 2, kind, s + i)], bits)
+        elif f in ("bgra", "rgba", "argb", "abgr"):
             if mode == "box" and rng.random() < 0.3:
                 sw, sh = rng.choice([(2, 2), (3, 5), (37, 21)])  # packed planes may be odd and tiny
             src = S.frame(f, [(sw, sh, 4, rng.choice(["premul", "noise", "smooth"]), s + i)], bits)

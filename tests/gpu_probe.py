@@ -15,7 +15,8 @@ BLEND_MODE = os.environ.get("PROBE_BLEND", "screen")
 
 
 def stack(kind, bits):
-    t = {"mix_blend": {}, "uyvy": dict(opacity=0.8),"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
+    t = {"mix_blend": {}, "uyvy": dict(opacity=0.8), "g_uyvy_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
+         "g_uyvy_rot": dict(opacity=0.8, angle=0.05),"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
          "levels": dict(opacity=0.7, **S.LEVELS), "bgra": dict(opacity=0.8),
          # general-kernel paths: scaled (axis-aligned), rotated, perspective, unit-scale with a blend mode
          "g_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]), "g_rot": dict(opacity=0.8, angle=0.05),
@@ -28,7 +29,7 @@ def stack(kind, bits):
     ops = []
     for i in range(NL):
         spec = S.bgra(W, H, "premul", 500 + i, bits=bits) if "bgra" in kind else S.ycbcr(W, H, SUB, "video", 500 + i, bits=bits)
-        if kind == "uyvy":  # what SDI capture delivers: one U Y0 V Y1 buffer bound twice
+        if "uyvy" in kind:  # what SDI capture delivers: one U Y0 V Y1 buffer bound twice
             spec = S.frame("uyvy", [(W, H, 2, "video", 500 + i)], bits)
         if kind == "mix_blend":  # a MIX pair inside a blend-mode layer: the kernels with TWO RGBA temporaries
             other = S.bgra(W, H, "premul", 700 + i, bits=bits)

@@ -290,10 +290,13 @@ def test_box_fuzz_scenes_are_planned_for_the_fast_kernels_sampled_bodies(bits):
         for o in ops:
             if o.kind == K.KOP_DRAW_PLANES and o.fast_class == K.FC_SAMPLED:
                 n_sampled += 1
-                base = 16 if o.planes[0].bits == 16 else 12
-                assert base <= o.fetch_body < base + 4 and not o.flags & K.KF_INVERT
-                assert all(o.planes[n].w >= 2 for n in range(o.nplanes))
-                assert bool(o.flags & K.KF_UNIT_SCALE) == bool((o.fetch_body - base) & 2)
+                assert not o.flags & K.KF_INVERT and all(o.planes[n].w >= 2 for n in range(o.nplanes))
+                if o.pixel_format == 10:  # uyvy: FB_RECT_UYVY8 (+ 1 at unit scale)
+                    assert o.fetch_body - 20 == int(bool(o.flags & K.KF_UNIT_SCALE))
+                else:
+                    base = 16 if o.planes[0].bits == 16 else 12
+                    assert base <= o.fetch_body < base + 4
+                    assert bool(o.flags & K.KF_UNIT_SCALE) == bool((o.fetch_body - base) & 2)
                 n_unit += bool(o.flags & K.KF_UNIT_SCALE)
                 n_axis += bool(o.flags & K.KF_AXIS)
     assert n_sampled > 150 and n_axis > 100 and n_unit > 20, (n_sampled, n_axis, n_unit)
