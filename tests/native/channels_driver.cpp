@@ -4,8 +4,12 @@
  * drive their mixers in the reference (core/video_channel.cpp:125-193). bench.py drives channels from one Python
  * thread, which tops out near 25 000 submissions a second; this measures what the runtime itself sustains.
  *
- *   channels_driver <channels> <frames per channel> [width height [timed]]   ->  one JSON line
+ *   channels_driver <channels> <frames per channel> [width height [timed [churn]]]   ->  one JSON line
  *   timed = 0: frames without the hipEvent pair that feeds a diagnostics graph (CGHIP_RENDER_UNTIMED)
+ *   churn = 1: lifetime stress. Every tick one source frame of every channel is created anew (pinned buffer, upload) and
+ *              the one it replaces is destroyed right after the frame that used it was submitted, i.e. while its
+ *              upload and the kernels reading it may still be in flight; the last frame of every channel is read back
+ *              and must equal the first one byte for byte (the sources never change content)
  */
 #include <atomic>
 #include <chrono>
@@ -67,6 +71,8 @@ int main(int argc, char** argv)
     const int channels = argc > 1 ? std::atoi(argv[1]) : 32, frames = argc > 2 ? std::atoi(argv[2]) : 500;
     const int W = argc > 4 ? std::atoi(argv[3]) : 1920, H = argc > 4 ? std::atoi(argv[4]) : 1080;
     const int timed = argc > 5 ? std::atoi(argv[5]) : 1;
+    const int churn = argc > 6 ? std::atoi(argv[6]) : 0;
+    std::atomic<int> mismatches{0};
     if (cghost_device_count() < 1) {
         std::fprintf(stderr, "no HIP device\n");
         return 2;
@@ -101,8 +107,17 @@ int main(int argc, char** argv)
                 CK(cghost_frame_create(m, CGHIP_PF_BGRA, 1, &p, nullptr, 0, &fr[k]));
             }
             const cghip_format fmt{W, H, W, H, 8, 0};
-            auto submit = [&](int tick) {
-                const double    delta = (tick % 25) / 25.0; /* transition_producer.cpp:159-163 */
+            void*              stale = nullptr;
+            auto submit = [&](int tick, int readback = 0) {
+                if (churn) { /* replace source tick % 3; the old frame goes right after this submission */
+                    const int    k = tick % 3;
+                    void*        fresh = nullptr;
+                    cghost_plane p{W, H, 4, 8, src[k].data()};
+                    CK(cghost_frame_create(m, CGHIP_PF_BGRA, 1, &p, nullptr, 0, &fresh));
+                    std::swap(fresh, fr[k]);
+                    stale = fresh;
+                }
+                const double    delta = churn ? 0.4 : (tick % 25) / 25.0; /* transition_producer.cpp:159-163 */
                 cghip_transform bg = identity(), layer = identity(), a = identity(), b = identity();
                 bg.layer_depth = 1, layer.layer_depth = 1;
                 a.is_mix = b.is_mix = 1, a.opacity = 1.0 - delta, b.opacity = delta;
@@ -112,7 +127,11 @@ int main(int argc, char** argv)
                 CK(cghost_mixer_push(m, &b)), CK(cghost_mixer_visit_frame(m, fr[2])), CK(cghost_mixer_pop(m));
                 CK(cghost_mixer_pop(m));
                 void* pending = nullptr;
-                CK(cghost_mixer_render_async(m, &fmt, 0, &pending));
+                CK(cghost_mixer_render_async(m, &fmt, readback, &pending));
+                if (stale) {
+                    cghost_frame_destroy(stale);
+                    stale = nullptr;
+                }
                 return pending;
             };
             auto run = [&](int n) { /* two frames in flight, like core::mixer (mixer.cpp:85-91) */
@@ -143,9 +162,19 @@ int main(int argc, char** argv)
                     cv.wait(lk, [&] { return go; });
                 }
             }
+            std::vector<uint8_t> first, last;
+            if (churn) {
+                first.resize((size_t)W * H * 4), last.resize(first.size());
+                CK(cghost_future_get(submit(0, 1), first.data(), first.size(), nullptr));
+            }
             run(frames);
             if (++done == channels)
                 t1 = std::chrono::steady_clock::now();
+            if (churn) {
+                CK(cghost_future_get(submit(frames, 1), last.data(), last.size(), nullptr));
+                if (first != last)
+                    ++mismatches;
+            }
             for (int k = 0; k < 3; ++k)
                 cghost_frame_destroy(fr[k]);
             cghost_mixer_destroy(m);
@@ -158,5 +187,7 @@ int main(int argc, char** argv)
                 "\"wait_us_per_frame\": %.1f}\n",
                 W, H, channels, timed, frames, s, channels * (double)frames / s, frames / s,
                 submit_ns / 1e3 / ((double)channels * frames), wait_ns / 1e3 / ((double)channels * frames));
-    return 0;
+    if (churn)
+        std::printf("{\"churn\": 1, \"channels_with_a_changed_frame\": %d}\n", mismatches.load());
+    return mismatches.load() ? 3 : 0;
 }

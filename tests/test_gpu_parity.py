@@ -544,3 +544,19 @@ def test_long_rundown_with_many_key_layers(mixer):
     ref = S.run_oracle(sc, "cpu")
     st = S.diff_stats(got, ref)
     assert st["max"] <= 1 and st["gt0"] <= 1e-4, st  # levels gamma 1.2: v_log/v_exp vs powf
+
+
+@pytest.mark.gpu
+def test_native_channel_threads_with_frame_churn():
+    """Lifetime stress through libcghost.so from native threads (tests/native/channels_driver.cpp, churn mode): 8 channel
+    threads, every tick one source frame per channel is created anew (pinned buffer + upload) and the frame it replaces
+    destroyed while its upload and the kernels reading it may still be in flight. Nothing may crash or hang and the
+    last frame of every channel must equal the first byte for byte. (What the pools, the per-plane ready events and the
+    planes' hold on their uploader are for: ADVICE round 1.)"""
+    import json, os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "channels_driver")
+    assert os.path.exists(exe), "tests/native/channels_driver is missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, "8", "150", "640", "360", "1", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    assert lines[0]["channels"] == 8 and lines[-1] == {"churn": 1, "channels_with_a_changed_frame": 0}
