@@ -1521,6 +1521,29 @@ DEV void fetch_uyvy8(const HotOp& op, int sx, int sy, f4 col[4])
     }
 }
 
+/* source colours of four pixels from one 8-bit plane of 1 channel (gray, luma) or 3 channels (bgr, rgb) at unit
+ * scale: the plane's texels as GL returns them (gl_texel), then the format's swizzle (shader.frag:485,499-505) - the
+ * two functions the general kernel's per-format path uses */
+DEV void fetch_bytes8(const HotOp& op, int sx, int sy, f4 col[4])
+{
+    const float sc = 1.0f / 255.0f;
+    if (op.pixel_format == 8 || op.pixel_format == 9) { /* wave-uniform: 12 bytes = four B,G,R texels */
+        const GB       row = row_base(op.ptr0, sy, op.w0, 3u);
+        const uint32_t a = load_at<uint32_t>(row, (uint32_t)sx * 3u), b = load_at<uint32_t>(row, (uint32_t)sx * 3u + 4u),
+                       c = load_at<uint32_t>(row, (uint32_t)sx * 3u + 8u);
+        const uint32_t t[4] = {a & 0xffffffu, (a >> 24) | ((b & 0xffffu) << 8), (b >> 16) | ((c & 0xffu) << 16), c >> 8};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            col[i] = swizzle_format(op.pixel_format, gl_texel(3, (float)(t[i] & 0xff) * sc, (float)((t[i] >> 8) & 0xff) * sc,
+                                                              (float)((t[i] >> 16) & 0xff) * sc, 0.0f));
+    } else {
+        const uint32_t v = load_at<uint32_t>(row_base(op.ptr0, sy, op.w0, 1u), (uint32_t)sx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            col[i] = swizzle_format(op.pixel_format, gl_texel(1, (float)((v >> (8 * i)) & 0xff) * sc, 0.0f, 0.0f, 0.0f));
+    }
+}
+
 /* ---- the same for 16-bit planes in 16-bit frames (relaxed numerics, see divf) ----
  * Between the sample codes and the colour there is nothing but affine maps: code / 65535, the 1/4 - 3/4 lerps of the
  * half-resolution chroma planes, Y' = 1.164 (255 Y - 16), the matrix, / 255 (shader.frag:441-467). Composed:
@@ -2197,6 +2220,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                     fetch_rect16<true, true>(op, load_hot_g<false>(op), h.ax0, h.ax1, opaque_v(px0), opaque_s(y), col, cover);
                 break;
             case FB_UYVY8: fetch_uyvy8(h, sx, SY, col); break;
+            case FB_BYTES8: fetch_bytes8(h, sx, SY, col); break;
             case FB_PACKED8: fetch_packed<8>(h, sx, SY, col); break;
             case FB_PACKED16: fetch_packed<16>(h, sx, SY, col); break;
             case FB_PLANAR8 + 0: fetch_planar<8, 0, 0>(h, sx, SY, red_only, col); break;
@@ -2233,7 +2257,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 col[i] = sel4((uint32_t)(px0 + i - h.ax0) < span, col[i], f4{0, 0, 0, 0});
             });
         }
-        if (SAMPLED && h.fetch_body >= FB_RECT8) { /* after the adjustments, which turn zero into something else */
+        if (SAMPLED && h.fetch_body >= FB_RECT8 && h.fetch_body < FB_SAMPLED_END) { /* after the adjustments, which turn zero into something else */
             static_for<0, P>([&](auto I) {
                 constexpr int i = decltype(I)::value;
                 col[i] = sel4((cover >> i) & 1u, col[i], f4{0, 0, 0, 0});

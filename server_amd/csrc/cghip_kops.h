@@ -42,6 +42,7 @@ enum KFastClass : int32_t {
     FC_PACKED = 1, /* one 4-channel plane (bgra / rgba / argb / abgr), unit scale */
     FC_PLANAR = 2, /* ycbcr / ycbcra planes of one bit depth, chroma at 1/1 or 1/2 per axis, unit scale */
     FC_SURFACE = 3, /* KOP_DRAW_SURFACE: a layer / mix temporary composited 1:1 (any blend mode, either keyer) */
+    FC_BYTES   = 6, /* gray, luma, bgr, rgb: one 8-bit plane of 1 or 3 channels at unit scale */
     FC_UYVY    = 5, /* 8-bit uyvy at unit scale: one buffer bound as RG8 w x h and RGBA8 (w/2) x h */
     FC_SAMPLED = 4  /* planes in one of the straight-line sampling layouts (KSampleClass), axis-aligned box at
                        any scale or 1:1 off the 4-texel grid: four bilinear fetches per lane, coverage per pixel */
@@ -58,6 +59,8 @@ enum KFetchBody : int32_t {
     FB_UYVY8    = 11, /* FC_UYVY */
     FB_RECT16   = 16, /* the same four for 16-bit planes (fp32 filter weights) */
     FB_RECT_UYVY8 = 20, /* and for 8-bit uyvy (SC_UYVY8): + 1 if KF_UNIT_SCALE */
+    FB_SAMPLED_END = 22, /* [FB_RECT8, FB_SAMPLED_END): the sampled bodies, compiled into the kernels' _s / _x instances */
+    FB_BYTES8   = 24, /* FC_BYTES: gray / luma (1 channel) and bgr / rgb (3 channels), 8-bit, unit scale */
     FB_RECT8    = 12  /* FC_SAMPLED with KF_AXIS or KF_UNIT_SCALE and 8-bit planes: + 0 ycbcr(a) planes, + 1 one packed
                          plane, + 2 if KF_UNIT_SCALE (a 1:1 source off the aligned bodies' 4-texel grid) */
 };

@@ -213,6 +213,7 @@ static void classify_fast(KOp& op, int frame_w)
     const bool wide = op.planes[0].bits == 16;
     op.fetch_body   = op.fast_class == FC_SURFACE   ? (int)FB_SURFACE
                       : op.fast_class == FC_UYVY    ? (int)FB_UYVY8
+                      : op.fast_class == FC_BYTES   ? (int)FB_BYTES8
                       : op.fast_class == FC_SAMPLED ? (op.sample_class == SC_UYVY8
                                            ? (int)FB_RECT_UYVY8 + ((op.flags & KF_UNIT_SCALE) ? 1 : 0)
                                            : (wide ? (int)FB_RECT16 : (int)FB_RECT8) +
@@ -280,6 +281,11 @@ static void classify_fast_draw(KOp& op, int frame_w)
     const int pf = op.pixel_format;
     if ((pf >= 1 && pf <= 4) && op.nplanes == 1 && p0.channels == 4) {
         op.fast_class = FC_PACKED;
+        return;
+    }
+    if ((pf == 0 || pf == 7 || pf == 8 || pf == 9) && op.nplanes == 1 && p0.bits == 8 &&
+        p0.channels == ((pf == 8 || pf == 9) ? 3 : 1)) { /* gray, luma, bgr, rgb (shader.frag:485,499-505) */
+        op.fast_class = FC_BYTES;
         return;
     }
     if (pf == 10 && op.nplanes == 2) { /* uyvy: both planes are views of one buffer (av_util.cpp:163-171) */
@@ -669,7 +675,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             const double fused = o.fused ? (k == 0 ? 1.5 : 1.7) : 0.0; /* the composite that rides on the item */
             if (k == 0)
                 return (o.kind == KOP_DRAW_SURFACE ? 4.4 : (planes && !(o.flags & KF_RECT)) ? 6.0 : 4.8) + fused;
-            if (planes && o.fetch_body >= FB_RECT8)
+            if (planes && o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END)
                 return (o.fetch_body >= FB_RECT_UYVY8 ? 3.2 : ((o.fetch_body - FB_RECT8) & 1 ? 2.6 : 3.5) * (o.fetch_body >= FB_RECT16 ? 1.15 : 1.0)) +
                        (temp ? 1.5 : 0.0) + fused;
             if (o.kind == KOP_DRAW_SURFACE)
@@ -765,7 +771,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         for (int i = sg.first; i < sg.first + sg.count && sg.fast; ++i) {
             const KOp& o = ops[(size_t)i];
             if (o.kind == KOP_DRAW_PLANES)
-                sg.ext = std::max(sg.ext, o.fused ? 2 : o.fetch_body >= FB_RECT8 ? 1 : 0);
+                sg.ext = std::max(sg.ext, o.fused ? 2 : (o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END) ? 1 : 0);
         }
         sg.load_mask  = touched & in_mem;
         sg.store_mask = written & ~zero & later;

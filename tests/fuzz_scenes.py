@@ -115,10 +115,12 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     s = 9000 + 131 * seed
     for i in range(rng.randint(1, 7)):
         f = rng.choice(["bgra", "rgba", "argb", "abgr", "ycbcr420", "ycbcr422", "ycbcr444", "ycbcra444", "ycbcra422", "ycbcra420",
-                        "solid"] + (["uyvy"] if bits == 8 else []))  # uyvy: what SDI capture delivers (8-bit only)
+                        "solid"] + (["uyvy", "gray", "luma", "bgr", "rgb"] if bits == 8 else []))  # 8-bit only bodies
         kind = rng.choice(["smooth", "noise", "video"])
-        if f == "uyvy":
+        if f == "uyvy":  # what SDI capture delivers
             src = S.frame("uyvy", [(W, H, 2, kind, s + i)], bits)
+        elif f in ("gray", "luma", "bgr", "rgb"):
+            src = S.frame(f, [(W, H, 1 if f in ("gray", "luma") else 3, kind if kind != "video" else "smooth", s + i)], bits)
         elif f == "solid":  # the colour producer: one 1x1 texel stretched over a rectangle on 4-pixel columns
             src = S.frame(rng.choice(["bgra", "rgba", "argb", "abgr"]), [(1, 1, 4, "noise", s + i)], bits)
         elif f in ("bgra", "rgba", "argb", "abgr"):

@@ -38,7 +38,7 @@ class KOp(C.Structure):
 KOP_CLEAR, KOP_DRAW_PLANES, KOP_DRAW_SURFACE = 0, 1, 2
 (KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE,
  KF_SOLID, KF_EDGE, KF_RED_ONLY, KF_AXIS) = [1 << i for i in range(14)]
-FC_NONE, FC_PACKED, FC_PLANAR, FC_SURFACE, FC_SAMPLED, FC_UYVY = range(6)
+FC_NONE, FC_PACKED, FC_PLANAR, FC_SURFACE, FC_SAMPLED, FC_UYVY, FC_BYTES = range(7)
 KS_RGBA0, KS_RGBA1, KS_RGBA2, KS_KEY0, KS_KEY1 = range(5)
 
 
