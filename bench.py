@@ -233,6 +233,10 @@ def main():
     # that happened inside the first device_sync(), between the warmup steps and the timed region, the GPU sat idle for
     # that long and the 20 timed launches that followed ran 0.21 -> 0.26 ms (the second process on the same box: 0.21).
     device_sync()
+    # ... and so are the communicators: the first collective of a process group sets them up (seconds with RCCL), which
+    # must not happen between the warmup steps and the timed region either
+    barrier()
+    allreduce_max(0.0)
     ndev = A.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the mixer has no CPU fallback)")
