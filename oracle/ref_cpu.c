@@ -241,11 +241,20 @@ static v3 ContrastSaturationBrightness(v4 color, float brt, float sat, float con
     return c;
 }
 
+/* Sensitivity analysis only (tests/test_gpu_parity.py): GLSL leaves pow's last bits to the implementation (llvmpipe
+ * evaluates a polynomial exp2(log2(x) * y), gfx950 v_exp_f32(y * v_log_f32(x)), this file libm's powf). This knob moves
+ * every pow result of the restatement by n ulps; a sample whose final value changes under it is one where the scene
+ * amplifies those bits (a blend mode or chroma key comparing against a threshold). Never on in a parity comparison. */
+static int g_pow_ulps = 0;
+void       cpuref_set_pow_ulps(int n) { g_pow_ulps = n; }
+
 /* shader.frag:76-86 */
 static float levels1(float c, float min_in, float gamma, float max_in, float min_out, float max_out)
 {
     float r = fminf_(fmaxf_(c - min_in, 0.0f) / (max_in - min_in), 1.0f);
     r       = powf(r, 1.0f / gamma);
+    for (int i = 0; i < abs(g_pow_ulps); ++i)
+        r = nextafterf(r, g_pow_ulps > 0 ? 2.0f : -1.0f);
     return mixf(min_out, max_out, r);
 }
 
