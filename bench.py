@@ -41,25 +41,31 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not os.environ.get("CGHIP_DIST_FORCE_GROUP"):  # (set: a one-rank group, to rehearse the RCCL path)
         return rank, world, local_rank, (lambda: None), (lambda x: x)
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
     use_gpu = torch.cuda.is_available()
     ndev = torch.cuda.device_count() if use_gpu else 0
     if use_gpu:
         torch.cuda.set_device(local_rank % ndev)  # a rehearsal may run more ranks than the box has GPUs
     backend = os.environ.get("CGHIP_DIST_BACKEND", "nccl" if use_gpu else "gloo")
-    try:
-        dist.init_process_group(backend=backend)
+    try:  # the rank's device is named, not guessed from the rank number
+        kw = {"device_id": torch.device("cuda", local_rank % ndev)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, **kw)
     except Exception:
         backend = "gloo"
         dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank % ndev) if (backend == "nccl") else torch.device("cpu")
 
     def barrier():
-        dist.barrier()
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank % ndev])
+        else:
+            dist.barrier()
 
     def allreduce_max(x):
         t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
@@ -259,8 +265,9 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = run_steps_channels(chs, args.steps)
     device_sync()
-    barrier()
-    dt = allreduce_max(time.perf_counter() - t0)
+    t1 = time.perf_counter()  # this rank's K steps are complete; the closing barrier's own latency (a collective of some
+    barrier()                 # 0.1 ms against 20 steps of 0.2 ms) is not part of any rank's work
+    dt = allreduce_max(t1 - t0)  # every rank started at the opening barrier: the job took as long as its slowest rank
 
     alg_bytes = S.algorithmic_bytes(scene)
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
@@ -332,9 +339,10 @@ def main():
         }
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if world > 1 or os.environ.get("CGHIP_DIST_FORCE_GROUP"):
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
