@@ -11,8 +11,11 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBCGHIP = os.path.join(HERE, "libcghip.so")
-LIBCGHOST = os.path.join(HERE, "libcghost.so")
+# CGHIP_LIB_DIR: another build of the SAME two libraries, e.g. the sanitizer builds of `make sanitize`
+# (tests/run_sanitized.sh); never a different implementation - there is none
+LIBDIR = os.environ.get("CGHIP_LIB_DIR") or HERE
+LIBCGHIP = os.path.join(LIBDIR, "libcghip.so")
+LIBCGHOST = os.path.join(LIBDIR, "libcghost.so")
 
 PF = dict(gray=0, bgra=1, rgba=2, argb=3, abgr=4, ycbcr=5, ycbcra=6, luma=7, bgr=8, rgb=9, uyvy=10, count=11,
           invalid=12)

@@ -1093,7 +1093,8 @@ extern "C" int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* su
         *full = (plan.full ? 1 : 0) | (plan.fast ? 2 : 0) | ((int)plan.segments.size() << 8);
     if (kops_out) {
         const int n = std::min(capacity, (int)plan.ops.size());
-        std::memcpy(kops_out, plan.ops.data(), (size_t)n * sizeof(KOp));
+        if (n > 0) /* an empty vector's data() may be null, which memcpy must not be handed even for 0 bytes */
+            std::memcpy(kops_out, plan.ops.data(), (size_t)n * sizeof(KOp));
     }
     return CGHIP_OK;
 }
