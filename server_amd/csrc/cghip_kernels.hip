@@ -1847,6 +1847,23 @@ DEV float lerp_pairs8(uint32_t top, uint32_t bot, int wx, int wy) /* two 2-texel
     const int a = lerp8s((int)(top & 0xff), (int)(top >> 8), wx), b = lerp8s((int)(bot & 0xff), (int)(bot >> 8), wx);
     return (float)lerp8s(a, b, wy);
 }
+/* Two lerp8s at once on words of the form 0x00XX00XX (one 8-bit sample per 16-bit half) that share a weight - Cb and Cr of
+ * a pixel always do: a + (((b - a) * w + 128) >> 8) = (a * (256 - w) + b * w + 128) >> 8, the sum is at most 255 * 256 +
+ * 128 < 2^16, so the halves never carry into each other and each is exactly lerp8s of its samples (weight 256 of the
+ * edge trick included). UNSHIFTED: the two results sit in bytes 1 and 3. */
+DEV uint32_t lerp8x2_raw(uint32_t a, uint32_t b, uint32_t w, uint32_t iw)
+{
+    return __umul24(a, iw) + __umul24(b, w) + 0x00800080u;
+}
+/* the Cb and Cr samples of a pixel from their four tap pairs (two texels per 16-bit load, zero-extended) */
+DEV void lerp_chroma8(uint32_t cbt, uint32_t cbb, uint32_t crt, uint32_t crb, int wx, int wy, float& Cb, float& Cr)
+{
+    const uint32_t w = (uint32_t)wx, iw = 256u - w;
+    const uint32_t top = (lerp8x2_raw(__builtin_amdgcn_perm(crt, cbt, 0x0c040c00u), __builtin_amdgcn_perm(crt, cbt, 0x0c050c01u), w, iw) >> 8) & 0x00FF00FFu;
+    const uint32_t bot = (lerp8x2_raw(__builtin_amdgcn_perm(crb, cbb, 0x0c040c00u), __builtin_amdgcn_perm(crb, cbb, 0x0c050c01u), w, iw) >> 8) & 0x00FF00FFu;
+    const uint32_t v   = lerp8x2_raw(top, bot, (uint32_t)wy, 256u - (uint32_t)wy);
+    Cb = (float)((v >> 8) & 0xffu), Cr = (float)(v >> 24);
+}
 template <bool PACKED, bool UNIT>
 DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, int y, f4 col[4], uint32_t& cover)
 {
@@ -1916,9 +1933,10 @@ DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, in
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const float   Y = lerp_pairs8(yt[i], yb[i], c0[i].wx, ry.wy) * sc;
-            const float   Cb = lerp_pairs8(bt[i], bb[i], c1[i].wx, rb.wy) * sc, Cr = lerp_pairs8(rt[i], rbm[i], c1[i].wx, rb.wy) * sc;
+            float         Cb, Cr;
+            lerp_chroma8(bt[i], bb[i], rt[i], rbm[i], c1[i].wx, rb.wy, Cb, Cr);
             const float   A = alpha ? lerp_pairs8(at[i], ab[i], c0[i].wx, ry.wy) * sc : 1.0f;
-            col[i] = ycbcra_to_rgba(Y, Cb, Cr, A, hd);
+            col[i] = ycbcra_to_rgba(Y, Cb * sc, Cr * sc, A, hd);
         });
     }
 }
@@ -1957,9 +1975,12 @@ DEV void fetch_rect_uyvy8(const KOp& op, const HotG& g, int ax0, int ax1, int px
         constexpr int i = decltype(I)::value;
         const int     wx0 = c0[i].wx, wx1 = c1[i].wx;
         const float   Y = (float)lerp8s(lerp8s((yt[i] >> 8) & 0xff, yt[i] >> 24, wx0), lerp8s((yb[i] >> 8) & 0xff, yb[i] >> 24, wx0), ry.wy);
-        const float   U = (float)lerp8s(lerp8s(ct[i].x & 0xff, ct[i].y & 0xff, wx1), lerp8s(cb[i].x & 0xff, cb[i].y & 0xff, wx1), rc.wy);
-        const float   V = (float)lerp8s(lerp8s((ct[i].x >> 16) & 0xff, (ct[i].y >> 16) & 0xff, wx1),
-                                        lerp8s((cb[i].x >> 16) & 0xff, (cb[i].y >> 16) & 0xff, wx1), rc.wy);
+        /* U and V sit in bytes 0 and 2 of a texel of the RGBA8 view: both lerped at once (lerp8x2_raw) */
+        const uint32_t w1 = (uint32_t)wx1, iw1 = 256u - w1, m = 0x00FF00FFu;
+        const uint32_t top = (lerp8x2_raw(ct[i].x & m, ct[i].y & m, w1, iw1) >> 8) & m;
+        const uint32_t bot = (lerp8x2_raw(cb[i].x & m, cb[i].y & m, w1, iw1) >> 8) & m;
+        const uint32_t uv  = lerp8x2_raw(top, bot, (uint32_t)rc.wy, 256u - (uint32_t)rc.wy);
+        const float    U = (float)((uv >> 8) & 0xffu), V = (float)(uv >> 24);
         col[i] = ycbcra_to_rgba(Y * sc, U * sc, V * sc, 1.0f, hd);
     });
 }
