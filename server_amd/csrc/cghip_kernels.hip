@@ -1912,7 +1912,7 @@ DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, in
         const bool    alpha = g.pixel_format == 6;
         const bool    hd = g.flags & KF_IS_HD;
         ColTaps       c0[4], c1[4];
-        uint32_t      yt[4], yb[4], bt[4], bb[4], rt[4], rbm[4], at[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+        uint32_t      yt[4], yb[4], bt[4], bb[4], rt[4], rbm[4];
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             c0[i] = col_taps(coord(s[i], sw0), g.w0), c1[i] = col_taps(coord(s[i], sw1), g.w1);
@@ -1923,21 +1923,26 @@ DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, in
             bt[i] = load_at<uint16_t>(rb.r0, c1[i].x), bb[i] = load_at<uint16_t>(rb.r1, c1[i].x);
             rt[i] = load_at<uint16_t>(rr.r0, c1[i].x), rbm[i] = load_at<uint16_t>(rr.r1, c1[i].x);
         });
-        if (alpha) { /* wave-uniform */
-            const RowTaps ra = row_taps(g.ptr3, iv0, g.w0, g.h0, 1u);
-            static_for<0, 4>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                at[i] = load_at<uint16_t>(ra.r0, c0[i].x), ab[i] = load_at<uint16_t>(ra.r1, c0[i].x);
-            });
-        }
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const float   Y = lerp_pairs8(yt[i], yb[i], c0[i].wx, ry.wy) * sc;
             float         Cb, Cr;
             lerp_chroma8(bt[i], bb[i], rt[i], rbm[i], c1[i].wx, rb.wy, Cb, Cr);
-            const float   A = alpha ? lerp_pairs8(at[i], ab[i], c0[i].wx, ry.wy) * sc : 1.0f;
-            col[i] = ycbcra_to_rgba(Y, Cb * sc, Cr * sc, A, hd);
+            col[i] = ycbcra_to_rgba(Y, Cb * sc, Cr * sc, 1.0f, hd);
         });
+        if (alpha) { /* wave-uniform, and rare (ycbcra): a second round trip of its own, so that the eight registers of
+                        its taps are not held (as zeros) through the three planes every ycbcr box has */
+            const RowTaps ra = row_taps(g.ptr3, iv0, g.w0, g.h0, 1u);
+            uint32_t      at[4], ab[4];
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                at[i] = load_at<uint16_t>(ra.r0, c0[i].x), ab[i] = load_at<uint16_t>(ra.r1, c0[i].x);
+            });
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                col[i].w = lerp_pairs8(at[i], ab[i], c0[i].wx, ry.wy) * sc;
+            });
+        }
     }
 }
 
@@ -2070,7 +2075,7 @@ DEV void fetch_rect16(const KOp& op, const HotG& g, int ax0, int ax1, int px0, i
         const bool     alpha = g.pixel_format == 6;
         const bool     hd = g.flags & KF_IS_HD;
         ColTapsF       c0[4], c1[4];
-        uint32_t       yt[4], yb[4], bt[4], bb[4], rt[4], rbm[4], at[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+        uint32_t       yt[4], yb[4], bt[4], bb[4], rt[4], rbm[4];
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             c0[i] = col_taps_f(coord(s[i], sw0), g.w0), c1[i] = col_taps_f(coord(s[i], sw1), g.w1);
@@ -2081,20 +2086,24 @@ DEV void fetch_rect16(const KOp& op, const HotG& g, int ax0, int ax1, int px0, i
             bt[i] = load_at<uint32_t>(rb.r0, c1[i].x * 2u), bb[i] = load_at<uint32_t>(rb.r1, c1[i].x * 2u);
             rt[i] = load_at<uint32_t>(rr.r0, c1[i].x * 2u), rbm[i] = load_at<uint32_t>(rr.r1, c1[i].x * 2u);
         });
-        if (alpha) { /* wave-uniform */
-            const RowTapsF ra = row_taps_f(g.ptr3, v0, g.w0, g.h0, 2u);
-            static_for<0, 4>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                at[i] = load_at<uint32_t>(ra.r0, c0[i].x * 2u), ab[i] = load_at<uint32_t>(ra.r1, c0[i].x * 2u);
-            });
-        }
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
             const float   Y = lerp_pairs16(yt[i], yb[i], c0[i], ry.wy);
             const float   Cb = lerp_pairs16(bt[i], bb[i], c1[i], rb.wy), Cr = lerp_pairs16(rt[i], rbm[i], c1[i], rb.wy);
-            const float   A = alpha ? lerp_pairs16(at[i], ab[i], c0[i], ry.wy) : 1.0f;
-            col[i] = ycbcra_to_rgba(Y, Cb, Cr, A, hd);
+            col[i] = ycbcra_to_rgba(Y, Cb, Cr, 1.0f, hd);
         });
+        if (alpha) { /* wave-uniform and rare: its own round trip (see fetch_rect8) */
+            const RowTapsF ra = row_taps_f(g.ptr3, v0, g.w0, g.h0, 2u);
+            uint32_t       at[4], ab[4];
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                at[i] = load_at<uint32_t>(ra.r0, c0[i].x * 2u), ab[i] = load_at<uint32_t>(ra.r1, c0[i].x * 2u);
+            });
+            static_for<0, 4>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                col[i].w = lerp_pairs16(at[i], ab[i], c0[i], ry.wy);
+            });
+        }
     }
 }
 
