@@ -113,8 +113,8 @@ typedef struct cghip_draw {
  * field renders themselves (modules/decklink/consumer/decklink_consumer.cpp:293-308,
  * modules/newtek/consumer/newtek_ndi_consumer.cpp:135-140). */
 #define CGHIP_RENDER_FIELD_ROWS_ONLY 0x2u
-/* No hipEvent pair around the frame's launches: cghip_ticket_kernel_ms reports 0. A channel that does not feed a
- * diagnostics graph saves one runtime call and one queue packet per frame. */
+/* No hipEvent pair around the frame's launches: cghip_ticket_kernel_ms reports -1 ("not measured", still CGHIP_OK). A
+ * channel that does not feed a diagnostics graph saves one runtime call and one queue packet per frame. */
 #define CGHIP_RENDER_UNTIMED 0x4u
 /* Surface slots one frame's draw list may name (slot 0 = the frame; every key / mix / layer temporary the renderer
  * creates is one more). Slots are bound to the kernel's register surfaces by liveness, so this only bounds the list. */
@@ -188,7 +188,8 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
 /* ---- tickets: replaces future<array<const uint8_t>>::get (common/future.h:9-27) --------------- */
 int cghip_ticket_wait(cghip_ticket* ticket, const uint8_t** data, size_t* size); /* needs CGHIP_RENDER_READBACK */
 int cghip_ticket_device_ptr(cghip_ticket* ticket, const void** device_ptr, size_t* size);
-int cghip_ticket_kernel_ms(cghip_ticket* ticket, float* ms, int* launches); /* hipEvent time of the compositor */
+/* hipEvent time of the frame's launches in ms; -1 for a frame rendered with CGHIP_RENDER_UNTIMED */
+int cghip_ticket_kernel_ms(cghip_ticket* ticket, float* ms, int* launches);
 int cghip_ticket_release(cghip_ticket* ticket);
 
 #ifdef __cplusplus

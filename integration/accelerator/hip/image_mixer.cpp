@@ -57,7 +57,10 @@ plane_ptr own(cghip_plane* p) { return plane_ptr(p, [](cghip_plane* q) { cghip_p
 struct uploaded
 {
     spl::shared_ptr<device>                                           home;
-    std::shared_ptr<uploaded>                                         origin; // routed copy: keeps its source alive
+    // routed copy: the origin's device and the pinned buffers its upload may still read (the C ABI retains the source
+    // planes). Never a pointer to the origin itself: its `routed` cache holds this copy, that would be a cycle.
+    std::shared_ptr<device>                                           origin_home;
+    std::vector<array<const std::uint8_t>>                            origin_sources;
     std::vector<array<const std::uint8_t>>                            sources; // before planes: destroyed after them
     std::vector<plane_ptr>                                            planes;
     std::mutex                                                        route_mutex;
@@ -74,7 +77,8 @@ struct uploaded
             if (r.first == dst->handle())
                 return r.second;
         auto copy    = std::make_shared<uploaded>(dst);
-        copy->origin = self;
+        copy->origin_home    = self->home;
+        copy->origin_sources = self->sources;
         for (auto& pl : self->planes) {
             cghip_plane* out = nullptr;
             check(cghip_plane_peer_copy_async(dst->handle(), pl.get(), &out), "cghip_plane_peer_copy_async");

@@ -62,6 +62,12 @@ struct cghip_device {
     std::atomic<int64_t> peer_copies{0}, peer_copy_bytes{0}; /* routed planes copied INTO this device */
     std::atomic<int64_t> uploads{0}, upload_bytes{0};        /* host-to-device plane uploads */
 
+    /* cghip_mixer_render_noalloc: pinned staging for a frame's op list and op masks, taken ONCE here at device set-up
+       (cghip_device_create), so that the call itself neither allocates nor makes the runtime stage or pin a pageable
+       source per call. Used under the GPU's noalloc lock. */
+    void*  noalloc_staging       = nullptr;
+    size_t noalloc_staging_bytes = 0;
+
     int  dev_alloc(size_t bytes, void** out);
     void dev_free(void* p, size_t bytes);
     int  pinned_alloc(size_t bytes, void** out);
@@ -90,13 +96,17 @@ struct cghip_plane {
 struct cghip_mixer {
     cghip_device* dev        = nullptr;
     int           channel_id = 0;
-    hipStream_t   stream     = nullptr; /* compositor + readback of this channel */
+    hipStream_t   stream     = nullptr; /* compositor of this channel */
     hipStream_t   ops_stream = nullptr; /* uploads a frame's op list while the previous frame is still compositing */
+    hipStream_t   readback_stream = nullptr; /* D2H of finished frames (device.cpp:264-302): frame n crosses PCIe while
+                                                frame n + 1 composites; on the compositor's stream its 33 - 66 MB copy
+                                                (0.65 - 1.3 ms) sat in front of the next 0.2 ms launch */
 };
 
 struct cghip_ticket {
     cghip_device*             dev   = nullptr;
     hipStream_t               stream = nullptr;
+    hipStream_t               readback_stream = nullptr; /* set when the frame's D2H was enqueued there */
     void*                     d_out = nullptr;
     size_t                    out_bytes = 0;
     void*                     h_out = nullptr; /* pinned, when CGHIP_RENDER_READBACK */

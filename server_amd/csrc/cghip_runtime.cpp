@@ -31,6 +31,10 @@ int fail_hip(hipError_t e, const char* what)
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+/* layout of the scratch array of cghip_mixer_render_noalloc: [ MAX_OPS KOps | op masks | hand-over surfaces ] */
+constexpr size_t NOALLOC_MASK_REGION = 512u << 10;
+static size_t    noalloc_ops_bytes() { return round_up((size_t)CGHIP_NOALLOC_MAX_OPS * sizeof(KOp), 256); }
+
 } // namespace cghip
 
 using namespace cghip;
@@ -184,6 +188,14 @@ int cghip_device_create(int gpu_index, cghip_device** out)
         delete d;
         return fail_hip(e, "hipGetSymbolAddress(scratch)");
     }
+    d->noalloc_staging_bytes = noalloc_ops_bytes() + NOALLOC_MASK_REGION;
+    e = hipHostMalloc(&d->noalloc_staging, d->noalloc_staging_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(d->upload_stream);
+        (void)hipStreamDestroy(d->peer_stream);
+        delete d;
+        return fail_hip(e, "hipHostMalloc(noalloc staging)");
+    }
     *out = d;
     return CGHIP_OK;
 }
@@ -235,6 +247,8 @@ int cghip_device_destroy(cghip_device* dev)
         (void)hipStreamDestroy(dev->upload_stream);
     if (dev->peer_stream)
         (void)hipStreamDestroy(dev->peer_stream);
+    if (dev->noalloc_staging)
+        (void)hipHostFree(dev->noalloc_staging);
     delete dev;
     return rc;
 }
@@ -509,6 +523,13 @@ int cghip_mixer_create(cghip_device* dev, int channel_id, cghip_mixer** out)
         if (e != hipSuccess)
             (void)hipStreamDestroy(m->stream);
     }
+    if (e == hipSuccess) {
+        e = hipStreamCreateWithFlags(&m->readback_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            (void)hipStreamDestroy(m->ops_stream);
+            (void)hipStreamDestroy(m->stream);
+        }
+    }
     if (e != hipSuccess) {
         delete m;
         return fail_hip(e, "hipStreamCreateWithFlags");
@@ -525,8 +546,10 @@ int cghip_mixer_destroy(cghip_mixer* mixer)
     (void)hipSetDevice(mixer->dev->gpu);
     (void)hipStreamSynchronize(mixer->ops_stream);
     (void)hipStreamSynchronize(mixer->stream);
+    (void)hipStreamSynchronize(mixer->readback_stream);
     (void)hipStreamDestroy(mixer->ops_stream);
     (void)hipStreamDestroy(mixer->stream);
+    (void)hipStreamDestroy(mixer->readback_stream);
     mixer->dev->mixers--;
     delete mixer;
     return CGHIP_OK;
@@ -539,6 +562,8 @@ static void ticket_free(cghip_ticket* t, hipStream_t also_drain = nullptr)
                          the events that normally order the release have not been recorded */
         (void)hipStreamSynchronize(also_drain);
         (void)hipStreamSynchronize(t->stream);
+        if (t->readback_stream)
+            (void)hipStreamSynchronize(t->readback_stream);
     }
     if (t->ev_done)
         (void)hipEventSynchronize(t->ev_done);
@@ -678,7 +703,14 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     }
     T_HIP(hipEventRecord(t->ev_stop, t->stream));
     if (flags & CGHIP_RENDER_READBACK) {
+        /* The D2H rides the channel's readback stream, ordered after the frame's last launch by ev_stop: the
+           compositor's stream is free for the next frame while this one crosses PCIe (the reference polls a fence every
+           2 ms on its one GL thread, device.cpp:264-302). d_out and h_out belong to this ticket alone, and ev_done, which
+           releases them, is recorded behind the copy - no other hazard. */
         T_TRY(dev->pinned_alloc(t->out_bytes, &t->h_out));
+        hipStream_t rs = mixer->readback_stream;
+        t->readback_stream = rs;
+        T_HIP(hipStreamWaitEvent(rs, t->ev_stop, 0));
         const int fm = format->field_mode;
         if ((flags & CGHIP_RENDER_FIELD_ROWS_ONLY) && (fm == 1 || fm == 2) && format->height > 1) {
             /* only the rows the kernel drew: a strided copy of every second row */
@@ -686,13 +718,12 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
             const size_t first = fm == 1 ? 0 : 1;
             const size_t rows  = ((size_t)format->height - first + 1) / 2;
             T_HIP(hipMemcpy2DAsync((char*)t->h_out + first * row, 2 * row, (const char*)t->d_out + first * row, 2 * row,
-                                   row, rows, hipMemcpyDeviceToHost, t->stream));
+                                   row, rows, hipMemcpyDeviceToHost, rs));
         } else {
-            T_HIP(hipMemcpyAsync(t->h_out, t->d_out, t->out_bytes, hipMemcpyDeviceToHost, t->stream));
+            T_HIP(hipMemcpyAsync(t->h_out, t->d_out, t->out_bytes, hipMemcpyDeviceToHost, rs));
         }
+        T_HIP(hipEventRecord(t->ev_done, rs));
     }
-    if (t->ev_done) /* every event record is a packet the queue works through between two launches */
-        T_HIP(hipEventRecord(t->ev_done, t->stream));
 #undef T_TRY
 #undef T_HIP
     dev->frames_rendered++;
@@ -727,18 +758,21 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
         return fail(CGHIP_ERR_INVALID, "device_out must be 16-byte aligned");
     if (plan.ops.size() > CGHIP_NOALLOC_MAX_OPS)
         return fail(CGHIP_ERR_UNSUPPORTED, "frame has more than CGHIP_NOALLOC_MAX_OPS (256) ops: use cghip_mixer_render_async");
-    const size_t mask_region = 512u << 10; /* the launches' op masks, behind the op list */
-    if (plan.masks.size() * sizeof(uint64_t) > mask_region)
+    const size_t mask_region = NOALLOC_MASK_REGION; /* the launches' op masks, behind the op list */
+    const size_t ops_bytes = plan.ops.size() * sizeof(KOp), masks_bytes = plan.masks.size() * sizeof(uint64_t);
+    if (masks_bytes > mask_region)
         return fail(CGHIP_ERR_UNSUPPORTED, "frame is too large or cut too often for cghip_mixer_render_noalloc's op-mask region");
     if (dev->gpu < 0 || dev->gpu >= 64)
         return fail(CGHIP_ERR_UNSUPPORTED, "gpu index beyond the scratch table");
+    if (!dev->noalloc_staging || dev->noalloc_staging_bytes < noalloc_ops_bytes() + mask_region)
+        return fail(CGHIP_ERR_INVALID, "device has no staging block for cghip_mixer_render_noalloc");
 
     CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
     void*  base = nullptr;
     size_t cap  = 0;
     CGHIP_TRY_HIP(cghip_scratch_address(dev->gpu, &base, &cap));
     /* lay the hand-over surfaces out behind the op list; refuse what does not fit */
-    const size_t ops_only   = round_up((size_t)CGHIP_NOALLOC_MAX_OPS * sizeof(KOp), 256);
+    const size_t ops_only   = noalloc_ops_bytes();
     const size_t ops_region = ops_only + mask_region;
     size_t       off        = ops_region;
     void*        spill[4]   = {nullptr, nullptr, nullptr, nullptr};
@@ -759,37 +793,56 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
 
     std::lock_guard<std::mutex> lock(g_noalloc_mu[dev->gpu]); /* one frame at a time in a GPU's scratch array */
     hipStream_t                 st = mixer->stream;
+    /* From here on work may be queued on `st` that reads the staging block and the scratch array: EVERY way out goes
+       through the stream synchronisation at the end, so that neither is handed to the next caller (nor the staging
+       block rewritten) while launches or copies of this frame, failed or not, are still in flight. */
+    hipError_t  e    = hipSuccess;
+    const char* what = "";
+#define NA_HIP(expr)                                                                                                   \
+    do {                                                                                                               \
+        if (e == hipSuccess) {                                                                                         \
+            e = (expr);                                                                                                \
+            if (e != hipSuccess)                                                                                       \
+                what = #expr;                                                                                          \
+        }                                                                                                              \
+    } while (0)
     for (cghip_plane* p : plan.planes) { /* uploads still in flight */
         cghip_plane* root = p->parent ? p->parent : p;
         if (!root->ready_seen.load(std::memory_order_acquire))
-            CGHIP_TRY_HIP(hipStreamWaitEvent(st, root->ready, 0));
+            NA_HIP(hipStreamWaitEvent(st, root->ready, 0));
     }
-    if (!plan.ops.empty()) /* pageable source: the runtime stages it itself; ordered on the compositor's stream */
-        CGHIP_TRY_HIP(hipMemcpyAsync(base, plan.ops.data(), plan.ops.size() * sizeof(KOp), hipMemcpyHostToDevice, st));
+    /* op list and masks go up from the device's pinned staging block (set up once, cghip_device_create) */
+    char* stage = (char*)dev->noalloc_staging;
+    if (ops_bytes) {
+        std::memcpy(stage, plan.ops.data(), ops_bytes);
+        NA_HIP(hipMemcpyAsync(base, stage, ops_bytes, hipMemcpyHostToDevice, st));
+    }
     const uint64_t* d_masks = (const uint64_t*)((const char*)base + ops_only);
-    if (!plan.masks.empty())
-        CGHIP_TRY_HIP(hipMemcpyAsync((void*)d_masks, plan.masks.data(), plan.masks.size() * sizeof(uint64_t),
-                                     hipMemcpyHostToDevice, st));
-    int        launches = 0;
-    hipError_t e        = hipSuccess;
+    if (masks_bytes) {
+        std::memcpy(stage + ops_only, plan.masks.data(), masks_bytes);
+        NA_HIP(hipMemcpyAsync((void*)d_masks, stage + ops_only, masks_bytes, hipMemcpyHostToDevice, st));
+    }
+    int launches = 0;
     for (const segment& sg : plan.segments) {
+        if (e != hipSuccess)
+            break;
         KSpill sp;
         sp.rgba1 = spill[0], sp.rgba2 = spill[1], sp.key0 = spill[2], sp.key1 = spill[3];
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
         sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
         sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp ? 1 : 0;
-        e = cghip_launch_composite((const KOp*)base + sg.first, sg.count, device_out, format->width, format->height,
-                                   format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 + sg.ext : 0, &sp,
-                                   sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, st);
-        if (e != hipSuccess)
-            break;
-        ++launches;
+        NA_HIP(cghip_launch_composite((const KOp*)base + sg.first, sg.count, device_out, format->width, format->height,
+                                      format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 + sg.ext : 0, &sp,
+                                      sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, st));
+        if (e == hipSuccess)
+            ++launches;
     }
-    /* the op list (host vector) and the scratch array must stay untouched until the launches are done */
+#undef NA_HIP
+    /* the one way out: staging block and scratch array stay untouched until everything queued above is done */
     const hipError_t es = hipStreamSynchronize(st);
     if (e != hipSuccess)
-        return fail_hip(e, "cghip_launch_composite");
+        return fail_hip(e, what);
     if (es != hipSuccess)
         return fail_hip(es, "hipStreamSynchronize");
     dev->frames_rendered++;
@@ -827,8 +880,8 @@ int cghip_ticket_kernel_ms(cghip_ticket* ticket, float* ms, int* launches)
     if (!ticket || !ms)
         return fail(CGHIP_ERR_INVALID, "bad arguments");
     CGHIP_TRY_HIP(hipEventSynchronize(ticket->ev_stop));
-    if (!ticket->ev_start) {
-        *ms = 0.0f;
+    if (!ticket->ev_start) { /* CGHIP_RENDER_UNTIMED: "not measured" is not "took 0 ms" */
+        *ms = -1.0f;
         if (launches)
             *launches = ticket->launches;
         return CGHIP_OK;

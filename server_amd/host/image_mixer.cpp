@@ -156,13 +156,17 @@ struct uploaded_registry
     }
 };
 
-struct uploaded : std::enable_shared_from_this<uploaded>
+struct uploaded
 {
     /* declared first = destroyed last: planes return their memory to their device's pools on release, and the pinned
        buffers an upload is still reading (`sources`) outlive the planes, whose release waits for that upload */
     std::shared_ptr<device>                home_keep;   /* the device the planes live on */
-    std::shared_ptr<uploaded>              origin_keep; /* routed copy: the frame it was copied from, with its pinned
-                                                           buffers, until the copy is gone */
+    /* routed copy: what of the frame it was copied from must outlive the copy - its device and the pinned buffers its
+       upload may still be reading (the C ABI itself retains the source PLANES until the copy is released). Handles
+       only, never the origin `uploaded` itself: the origin's `routed` cache holds this copy, and a strong pointer back
+       would keep both alive for ever (planes, pinned buffers and registry entries of every routed frame leaked). */
+    std::shared_ptr<device>                origin_home_keep;
+    std::vector<array<const std::uint8_t>> origin_sources;
     std::vector<array<const std::uint8_t>> sources;
     std::vector<plane_ptr>                 planes;
     cghip_device*                          home  = nullptr;
@@ -181,8 +185,9 @@ struct uploaded : std::enable_shared_from_this<uploaded>
                 return r.second;
         auto copy       = std::make_shared<uploaded>();
         copy->home      = dst;
-        copy->home_keep   = dst_dev;
-        copy->origin_keep = shared_from_this();
+        copy->home_keep        = dst_dev;
+        copy->origin_home_keep = home_keep;
+        copy->origin_sources   = sources;
         for (auto& pl : planes) {
             cghip_plane* out = nullptr; /* the copy retains its source plane (cghip.h) */
             check(cghip_plane_peer_copy_async(dst, pl.get(), &out), "cghip_plane_peer_copy_async");
@@ -575,8 +580,8 @@ struct image_mixer::impl : std::enable_shared_from_this<image_mixer::impl>
             std::size_t         size = 0;
             check(cghip_ticket_wait(owner.get(), readback ? &data : nullptr, &size), "cghip_ticket_wait");
             float ms = 0.0f;
-            if (cghip_ticket_kernel_ms(owner.get(), &ms, nullptr) == CGHIP_OK)
-                self->last_ms_ = ms;
+            if (cghip_ticket_kernel_ms(owner.get(), &ms, nullptr) == CGHIP_OK && ms >= 0.0f)
+                self->last_ms_ = ms; /* an untimed frame (-1) leaves the last measured value in place */
             if (!readback) { /* device-resident frame: hand out the device pointer, owner keeps it alive */
                 const void* dptr = nullptr;
                 check(cghip_ticket_device_ptr(owner.get(), &dptr, &size), "cghip_ticket_device_ptr");

@@ -198,7 +198,7 @@ class image_mixer final
     /* interlaced channels (format_desc.field_mode 1 / 2): read back only the rows of the rendered field; the
        consumer weaves two such frames (decklink_consumer.cpp:293-308). Halves the D2H traffic. */
     void                   set_field_rows_only(bool on);
-    void                   set_kernel_timing(bool on); /* false: no hipEvent pair per frame, last_kernel_ms() stays 0 */
+    void                   set_kernel_timing(bool on); /* false: no hipEvent pair per frame, last_kernel_ms() keeps its last measured value */
 
   private:
     struct impl;

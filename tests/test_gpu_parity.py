@@ -397,6 +397,9 @@ def test_routed_frame_is_peer_copied_once_per_device(mixer):
                                      S.layer(spec, opacity=0.6, fill_translation=[0.25, 0.25])])
         want = S.run_product(sc, mixer=other)
         before = other.device_info()["peer_copies"]
+        in_use = lambda i: (i["planes_live"], i["pinned_pool"]["bytes"] - i["pinned_pool"]["bytes_pooled"],
+                            i["device_pool"]["bytes"] - i["device_pool"]["bytes_pooled"])
+        base_home, base_other = in_use(mixer.device_info()), in_use(other.device_info())
         routed = mixer.create_frame(spec["fmt"], planes)  # lives on `mixer`'s device
         try:
             for tick in range(2):
@@ -423,6 +426,11 @@ def test_routed_frame_is_peer_copied_once_per_device(mixer):
             assert mixer.device_info()["peer_copies"] == home_before
         finally:
             mixer.destroy_frame(routed)
+        # Nothing of a routed frame may outlive it (the copy held its origin and the origin's cache held
+        # the copy, so planes, pinned buffers and peer copies of every routed frame leaked): with the frame destroyed
+        # and the frames that showed it complete, both devices are back where they started.
+        assert in_use(mixer.device_info()) == base_home, (in_use(mixer.device_info()), base_home)
+        assert in_use(other.device_info()) == base_other, (in_use(other.device_info()), base_other)
     finally:
         other.close()
 

@@ -42,6 +42,9 @@ def _render_both(m, sc, torch):
     for pool in ("device_pool", "pinned_pool"):
         assert after[pool]["blocks"] == before[pool]["blocks"] and after[pool]["bytes"] == before[pool]["bytes"], pool
     assert after["tickets_live"] == before["tickets_live"]
+    # ... and the device itself says the same: hipMemGetInfo's free bytes did not move across the call (what the
+    # library's counters cannot see: an allocation made by the runtime on its behalf, e.g. to stage a pageable copy)
+    assert after["hbm_free_bytes"] == before["hbm_free_bytes"], (before["hbm_free_bytes"], after["hbm_free_bytes"])
     got = buf.cpu().numpy().view(want.dtype).reshape(want.shape)
     return want, got, after["kernel_launches"] - before["kernel_launches"], cache
 
