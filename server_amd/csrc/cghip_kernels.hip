@@ -712,9 +712,13 @@ DEV f4 shade_blend(const P& op, f4 color, float lkey, float ykey, f4 back)
     if constexpr (MODE == MODE_RUNTIME)
         blend = op.blend_mode != 0;
     if (blend) { /* shader.frag:427-428 */
+        /* The two un-premultiply divides are correctly rounded in BOTH builds: they are where the shader amplifies
+           (rgb / alpha with alpha down to one code), and only blend-mode ops pay for them. With the 1-ulp a * rcp(b) of
+           the relaxed build it was unproven whether a 16-bit residual of 3 - 10 LSB16 at small alphas was the scene's
+           or this arithmetic's. */
         const float ba = back.w + 0.0000001f, fa = fore.w + 0.0000001f;
-        const f3    B = {divf<RXF>(back.x, ba), divf<RXF>(back.y, ba), divf<RXF>(back.z, ba)};
-        const f3    F = {divf<RXF>(fore.x, fa), divf<RXF>(fore.y, fa), divf<RXF>(fore.z, fa)};
+        const f3    B = {fdiv(back.x, ba), fdiv(back.y, ba), fdiv(back.z, ba)};
+        const f3    F = {fdiv(fore.x, fa), fdiv(fore.y, fa), fdiv(fore.z, fa)};
         f3          bc;
         if constexpr (MODE == MODE_RUNTIME)
             bc = get_blend_color(op.blend_mode, B, F);
@@ -746,9 +750,9 @@ DEV void shade_blend_mode4(const BlendArgs op, const f4 col[4], f4 D[4], const f
         c.x *= op.opacity, c.y *= op.opacity, c.z *= op.opacity, c.w *= op.opacity;
         fore[i] = f4{__builtin_fmaf(c.x, im, ia0), __builtin_fmaf(c.y, im, ia0), __builtin_fmaf(c.z, im, ia0),
                      __builtin_fmaf(c.w, im, ia0)};
-        const float ba = D[i].w + 0.0000001f, fa = fore[i].w + 0.0000001f;
-        B[i] = f3{divf<RXF>(D[i].x, ba), divf<RXF>(D[i].y, ba), divf<RXF>(D[i].z, ba)};
-        F[i] = f3{divf<RXF>(fore[i].x, fa), divf<RXF>(fore[i].y, fa), divf<RXF>(fore[i].z, fa)};
+        const float ba = D[i].w + 0.0000001f, fa = fore[i].w + 0.0000001f; /* exact divides in both builds: see shade_blend */
+        B[i] = f3{fdiv(D[i].x, ba), fdiv(D[i].y, ba), fdiv(D[i].z, ba)};
+        F[i] = f3{fdiv(fore[i].x, fa), fdiv(fore[i].y, fa), fdiv(fore[i].z, fa)};
     });
     const v12f r = get_blend_color4(op.blend_mode,
                                     v12f{B[0].x, B[0].y, B[0].z, B[1].x, B[1].y, B[1].z, B[2].x, B[2].y, B[2].z, B[3].x, B[3].y, B[3].z},

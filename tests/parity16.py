@@ -77,11 +77,15 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
     width times a texel difference of 65535): the input planes themselves moved by +-1 LSB16, uniformly, plane by plane
     and randomly. Too coarse a probe for smooth content: the YCbCr matrix alone turns +1 on every plane into +3.3 on
     blue.
-    Tier 3 - one LSB16 of an INTERMEDIATE render target: every UNORM store of every draw lands on a neighbouring code
-    with probability 1/2. The kernels of 16-bit frames evaluate the shader with fused multiply-adds and reciprocal
+    Tier 3 - one LSB16 of an INTERMEDIATE render target, deterministically: for every draw of the frame in turn, that
+    draw's UNORM stores land one code off at EVERY pixel - colour and alpha up, down, each alone, and against each other
+    (what a blend mode's rgb / alpha is most sensitive to, shader.frag:427-428) -, plus every store of every draw up /
+    down together. The kernels of 16-bit frames evaluate the shader with fused multiply-adds and reciprocal
     multiplies (server_amd/csrc/cghip_kernels.hip: divf), a few 1e-7 away from the exact sequence, so a few per cent of
-    their stores round to the neighbouring code; a later draw whose blend mode divides by alpha (shader.frag:427-428)
-    or whose contrast exceeds 2 turns that one LSB16 into three. The draw-by-draw rounding itself is kept."""
+    their stores round to the neighbouring code; a later draw whose blend mode divides by alpha or whose contrast
+    exceeds 2 turns that one LSB16 into three. The draw-by-draw rounding itself is kept. (Rounds 1 - 2 flipped stores
+    at random with four seeds: a statistical probe that could miss a pixel. This one cannot miss what ONE draw's LSB
+    is worth.)"""
     from oracle import oracle as O
     L = O.lib()
     base = ref.astype(np.int32)
@@ -103,12 +107,23 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
         for _name, fn in perturbations().items():
             mask |= _moved(sc, _perturbed(cache, fn), base, limit)
     if tier >= 3:
-        for seed in (1, 2, 3, 4, 0xFFFFFFFF, 0xFFFFFFFE):  # four random patterns, every store up, every store down
+        for seed in (0xFFFFFFFF, 0xFFFFFFFE):  # every store of every draw up / down
             L.cpuref_set_store_flip(seed)
             try:
                 mask |= _moved(sc, cache, base, limit)
             finally:
                 L.cpuref_set_store_flip(0)
+        L.cpuref_reset_draw_count()
+        S.run_oracle(sc, "cpu", cache)
+        ndraws = L.cpuref_draw_count()
+        try:
+            for draw in range(1, ndraws + 1):
+                # (colour, alpha) deltas: together, apart, and against each other
+                for dc, da in ((1, 1), (-1, -1), (1, 0), (-1, 0), (0, 1), (0, -1), (1, -1), (-1, 1)):
+                    L.cpuref_set_store_flip_draw(draw, dc, da)
+                    mask |= _moved(sc, cache, base, limit)
+        finally:
+            L.cpuref_set_store_flip_draw(0, 0, 0)
     return mask
 
 

@@ -238,9 +238,11 @@ def test_mixed_frame_is_cut_into_launches_by_the_default_policy(mixer, bits):
     assert sd["max"] == 0 if bits == 8 else (sd["max"] <= 1 and sd["gt0"] <= 5e-3), sd  # 16 bits: see above
     ref = S.run_oracle(sc, "cpu", cache)
     so = S.diff_stats(cut, ref)
-    assert so["max"] == 0 if bits == 8 else so["gt2"] <= 1e-3, so
-    if bits == 16:
-        P16.check(sc, cut, ref, cache, report="mixed_1080p_16bit")
+    if bits == 8:
+        assert so["max"] == 0, so
+    else:  # +-2 LSB16 as a maximum outside the scene's amplifying pixels, no pixel unexplained (tests/parity16.py)
+        st16 = P16.check(sc, cut, ref, cache, report="mixed_1080p_16bit")
+        assert st16["max_outside_amplifying"] <= P16.LIMIT and so["gt2"] <= 1e-3, (st16, so)
 
 
 FULL = [("config1", lambda: S.config1()), ("config2", lambda: S.config2()), ("config4", lambda: S.config4()),
