@@ -135,7 +135,7 @@ def lib():
         L.cpuref_set_fetch_delta.argtypes = [C.c_float] * 4
         L.cpuref_set_snap_fetch.argtypes = [C.c_int]
         L.cpuref_set_store_flip.argtypes = [C.c_uint]
-        L.cpuref_set_store_flip_draw.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.cpuref_set_store_flip_draw.argtypes = [C.c_int] * 5
         L.cpuref_draw_count.restype = C.c_int
         L.cpuref_set_pow_ulps.argtypes = [C.c_int]
         _lib = L

@@ -711,23 +711,25 @@ static void interpolate(const tri_setup* ts, int x, int y, float out[6])
 static unsigned g_store_flip = 0; /* 0 = off, else the seed */
 static unsigned g_draw_index = 0;
 void            cpuref_set_store_flip(unsigned seed) { g_store_flip = seed, g_draw_index = 0; }
-/* The deterministic form of the same probe (tests/parity16.py, tier 3): the stores of ONE draw (draws are counted from 1
- * in execution order since the last reset) land off their code at EVERY pixel: the colour samples (B, G, R of an RGBA
- * target, the single sample of a key target) by `delta_colour` codes, alpha by `delta_alpha`. One draw at a time, both
- * signs, colour and alpha together, apart and against each other (rgb / alpha of a blend mode, shader.frag:427-428, moves
- * most when they err in opposite directions): what one LSB16 of that draw's render target is worth at every pixel of
- * the final frame. draw 0 = off. */
-static int g_flip_draw = 0, g_flip_colour = 0, g_flip_alpha = 0;
-void       cpuref_set_store_flip_draw(int draw, int delta_colour, int delta_alpha)
+/* The deterministic form of the same probe (tests/parity16.py, tiers 3 and 4): the stores of ONE draw (draws are counted
+ * from 1 in execution order since the last reset) land off their code at EVERY pixel, each sample of the target's texel
+ * by its own delta (memory order B, G, R, A; a key target has the first one only). One draw at a time; the test walks the
+ * sign patterns: colour and alpha up, down, apart and against each other (rgb / alpha of a blend mode, shader.frag:
+ * 427-428, moves most when they err in opposite directions), and for the HSL modes, whose hue and saturation hang on
+ * DIFFERENCES between channels, every pattern of -1 / 0 / +1 over the four samples. What one LSB16 of that draw's
+ * render target is worth at every pixel of the final frame. draw 0 = off. */
+static int g_flip_draw = 0, g_flip_delta[4] = {0, 0, 0, 0};
+void       cpuref_set_store_flip_draw(int draw, int db, int dg, int dr, int da)
 {
-    g_flip_draw = draw, g_flip_colour = delta_colour, g_flip_alpha = delta_alpha, g_draw_index = 0;
+    g_flip_draw = draw, g_draw_index = 0;
+    g_flip_delta[0] = db, g_flip_delta[1] = dg, g_flip_delta[2] = dr, g_flip_delta[3] = da;
 }
 void cpuref_reset_draw_count(void) { g_draw_index = 0; }
 int  cpuref_draw_count(void) { return (int)g_draw_index; } /* draws executed since the last reset */
 static int store_flip(int x, int y, int k)
 {
     if (g_flip_draw) /* the deterministic probe */
-        return (unsigned)g_flip_draw == g_draw_index ? (k == 3 ? g_flip_alpha : g_flip_colour) : 0;
+        return (unsigned)g_flip_draw == g_draw_index ? g_flip_delta[k & 3] : 0;
     if (g_store_flip >= 0xFFFFFFFEu) /* every store one code up (..FF) / down (..FE) */
         return g_store_flip == 0xFFFFFFFFu ? 1 : -1;
     uint64_t z = ((uint64_t)g_store_flip << 48) ^ ((uint64_t)g_draw_index << 34) ^ ((uint64_t)y << 18) ^ ((uint64_t)x << 2) ^ (uint64_t)k;

@@ -1790,9 +1790,34 @@ DEV void fore_key4(const HotOp& op, const f4 col[4], const float K0[4], Fore& o)
     });
 }
 /* fore + ia * back, then the UNORM store (shader.frag:429-433,541) */
+#ifndef CGHIP_INPLACE_STORE
+#define CGHIP_INPLACE_STORE 0
+#endif
+/* The relaxed build's three fmas of quantize<16>(f + ia * s) (clamp as output modifier, magic-constant rounding, back to
+ * [0,1]) written so that the surface register is updated WHERE IT LIVES: left to the compiler the sixteen results of
+ * an op landed in whatever registers the source colour had freed and were copied into the loop-carried surface
+ * registers at the loop latch (16 v_mov per op and lane, 8 % of a plain layer's instructions). Tied operands leave it no
+ * choice. Same instructions, same constants (0x3f7fff00 = 65535/65536, 0x3f800080 = 65536/65535). */
+DEV void blend_store16_inplace(float& s, float ia, float f, float magic, float neg_md)
+{
+    asm("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(s) : "v"(ia), "v"(f));
+    asm("v_fmamk_f32 %0, %0, 0x3f7fff00, %1" : "+v"(s) : "v"(magic));
+    asm("v_fmamk_f32 %0, %0, 0x3f800080, %1" : "+v"(s) : "v"(neg_md));
+}
 template <int BITS>
 DEV void store_rgba4(const Fore& o, f4 S[4])
 {
+    if constexpr (RXF && BITS == 16 && CGHIP_INPLACE_STORE) {
+        const float magic = in_vgpr(Q<16>::magic), neg_md = in_vgpr(-Q<16>::magic * Q<16>::dequant);
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            blend_store16_inplace(S[i].x, o.ia[i], o.f[i].x, magic, neg_md);
+            blend_store16_inplace(S[i].y, o.ia[i], o.f[i].y, magic, neg_md);
+            blend_store16_inplace(S[i].z, o.ia[i], o.f[i].z, magic, neg_md);
+            blend_store16_inplace(S[i].w, o.ia[i], o.f[i].w, magic, neg_md);
+        });
+        return;
+    }
     static_for<0, 4>([&](auto I) {
         constexpr int i = decltype(I)::value;
         S[i] = f4{quantize<BITS>(o.f[i].x + o.ia[i] * S[i].x), quantize<BITS>(o.f[i].y + o.ia[i] * S[i].y),

@@ -11,6 +11,8 @@ a float filter weight's last bits are worth.
 within +-limit of the oracle at EVERY other pixel, and returns statistics for the report
 (tests/golden/parity16_report.json).
 """
+import itertools
+
 import numpy as np
 
 import scenes as S
@@ -96,13 +98,18 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
     finally:
         L.cpuref_set_snap_fetch(0)
     e = 1e-6
-    for delta in ((e, e, e, e), (-e, -e, -e, -e), (e, 0, 0, 0), (-e, 0, 0, 0), (0, 0, 0, e), (0, 0, 0, -e),
-                  (e, 0, 0, e), (0, 0, e, e)):
-        L.cpuref_set_fetch_delta(*delta)
-        try:
-            mask |= _moved(sc, cache, base, limit)
-        finally:
-            L.cpuref_set_fetch_delta(0.0, 0.0, 0.0, 0.0)
+    for snap in (0, 1):  # against the fetch as it is, and against the noise-free one: on max-contrast content the
+        # oracle's own filter noise (a few 1e-5) buries a delta of 1e-6, and a tie that only the noise-free fetch hits
+        # exactly - a hue EQUAL to the chroma key's target, shader.frag:360-366 - would go unseen (fuzzfast_7658)
+        for delta in ((e, e, e, e), (-e, -e, -e, -e), (e, 0, 0, 0), (-e, 0, 0, 0), (0, 0, 0, e), (0, 0, 0, -e),
+                      (e, 0, 0, e), (0, 0, e, e)):
+            L.cpuref_set_fetch_delta(*delta)
+            L.cpuref_set_snap_fetch(snap)
+            try:
+                mask |= _moved(sc, cache, base, limit)
+            finally:
+                L.cpuref_set_fetch_delta(0.0, 0.0, 0.0, 0.0)
+                L.cpuref_set_snap_fetch(0)
     if tier >= 2:
         for _name, fn in perturbations().items():
             mask |= _moved(sc, _perturbed(cache, fn), base, limit)
@@ -116,21 +123,24 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
         L.cpuref_reset_draw_count()
         S.run_oracle(sc, "cpu", cache)
         ndraws = L.cpuref_draw_count()
+        if tier == 3:  # (colour, alpha) deltas: together, apart, and against each other
+            patterns = [(c, c, c, a) for c, a in ((1, 1), (-1, -1), (1, 0), (-1, 0), (0, 1), (0, -1), (1, -1), (-1, 1))]
+        else:  # tier 4: every pattern of -1 / 0 / +1 over B, G, R, A (the HSL blend modes look at channel differences)
+            patterns = [p for p in itertools.product((-1, 0, 1), repeat=4) if any(p)]
         try:
             for draw in range(1, ndraws + 1):
-                # (colour, alpha) deltas: together, apart, and against each other
-                for dc, da in ((1, 1), (-1, -1), (1, 0), (-1, 0), (0, 1), (0, -1), (1, -1), (-1, 1)):
-                    L.cpuref_set_store_flip_draw(draw, dc, da)
+                for p in patterns:
+                    L.cpuref_set_store_flip_draw(draw, *p)
                     mask |= _moved(sc, cache, base, limit)
         finally:
-            L.cpuref_set_store_flip_draw(0, 0, 0)
+            L.cpuref_set_store_flip_draw(0, 0, 0, 0, 0)
     return mask
 
 
 REPORT = {}  # scene name -> stats; tests/conftest.py writes it to gpurun_out/parity16_report.json after a GPU session
 
 
-def check(sc, got, ref, cache, limit=LIMIT, unexplained_fraction=0.0, report=None, list_pixels=False, max_tier=3,
+def check(sc, got, ref, cache, limit=LIMIT, unexplained_fraction=0.0, report=None, list_pixels=False, max_tier=4,
           oracle_ref=None):
     """Asserts |got - ref| <= limit at every pixel that is not an amplifying pixel of the scene (at all but
     `unexplained_fraction` of the pixels, for comparisons between two rasterisers whose coverage and filter-boundary
@@ -140,9 +150,24 @@ def check(sc, got, ref, cache, limit=LIMIT, unexplained_fraction=0.0, report=Non
     `oracle_ref`: the probes are differences of the oracle against itself."""
     d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
     worst_px = d.max(axis=-1) if d.size else d
+    if d.size and (worst_px > limit).any() and oracle_ref is None:
+        # The oracle filters 16-bit textures like llvmpipe does: fp32 weights from fp32-interpolated coordinates. At a 1:1
+        # layer those weights are not exactly 0 but a few 1e-5 (one ulp of s = 0.57 times 516 texels), and on max-contrast
+        # noise that alone is worth 2 LSB16 - the oracle moves by 2 against ITSELF with that noise removed
+        # (cpuref_set_snap_fetch), which is what a GPU's fixed-point weights, and the HIP kernels' texel-index fetch of
+        # unit-scale layers, return. Both fetches are realisations of the reference pipeline, so a pixel passes when all its
+        # samples are within the limit of ONE of the two frames. (Found by tests/gpu_parity16_hunt.py: fuzzfast_4686, one
+        # pixel in 20 000 scenes, 3 from the oracle as it is, 1 from the noise-free one.)
+        from oracle import oracle as O
+        O.lib().cpuref_set_snap_fetch(1)
+        try:
+            snapped = S.run_oracle(sc, "cpu", cache).astype(np.int32)
+        finally:
+            O.lib().cpuref_set_snap_fetch(0)
+        worst_px = np.minimum(worst_px, np.abs(got.astype(np.int32) - snapped).max(axis=-1))
     st = {"max": int(d.max()) if d.size else 0, "gt0": float((d > 0).mean()) if d.size else 0.0,
           "gt2": float((d > limit).mean()) if d.size else 0.0, "pixels_gt2": int((worst_px > limit).sum()),
-          "tier": 0, "amplifying_pixels": 0, "max_outside_amplifying": int(d.max()) if d.size else 0}
+          "tier": 0, "amplifying_pixels": 0, "max_outside_amplifying": int(worst_px.max()) if d.size else 0}
     if report is not None:
         REPORT[report] = st
     if st["pixels_gt2"] == 0:
