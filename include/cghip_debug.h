@@ -50,6 +50,9 @@ void cghip_debug_fast_rows(int rows);
 /* Large launches of the 4-pixels-per-lane kernel number their tiles so that neighbouring tiles share an XCD's L2
  * (cghip_kernels.hip: xcd_block); on = tiles in dispatch order as in small launches, to measure the difference. */
 void cghip_debug_plain_tiles(int on);
+/* Launches whose draws all take one fetch body run a kernel instance compiled for that body alone
+ * (cghip_composite_fast_m); on = they run the kernel with all bodies, so tests can compare the two bit for bit. */
+void cghip_debug_no_mono_kernels(int on);
 
 #ifdef __cplusplus
 }

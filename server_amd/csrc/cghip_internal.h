@@ -130,6 +130,7 @@ struct segment {
     bool     fused = false;        /* holds a KOp::fused op */
     bool     one_temp = false;     /* full, but RGBA2 is never touched, loaded or stored */
     int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
+    int      mono = -1;            /* fast, not full, ext 0: the one fetch body all its draws take (KSpill::mono), else -1 */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
     int      gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0; /* pixel box the launch covers */
     /* op masks per band of the frame (KSpill::masks): offset into frame_plan::masks, in uint64 */

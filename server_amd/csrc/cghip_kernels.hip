@@ -1262,9 +1262,13 @@ DEV float in_vgpr(float x)
 struct LevelsV {
     float lv_min_input, lv_range, lv_inv_range, lv_inv_gamma, lv_min_output, lv_max_output;
     explicit DEV LevelsV(const KOp& o)
-        : lv_min_input(in_vgpr(o.lv_min_input)), lv_range(in_vgpr(o.lv_range)), lv_inv_range(in_vgpr(o.lv_inv_range)),
-          lv_inv_gamma(o.lv_inv_gamma), lv_min_output(o.lv_min_output), lv_max_output(o.lv_max_output)
-    { /* gamma and the output range feed wave-uniform tests first: they stay scalar until used */
+    { /* one batch of scalar loads and one wait (see ycoef16); gamma and the output range feed wave-uniform tests
+         first: they stay scalar until used */
+        float a = o.lv_min_input, b = o.lv_range, c = o.lv_inv_range, d = o.lv_inv_gamma, e = o.lv_min_output,
+              f = o.lv_max_output;
+        asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f));
+        lv_min_input = in_vgpr(a), lv_range = in_vgpr(b), lv_inv_range = in_vgpr(c);
+        lv_inv_gamma = d, lv_min_output = e, lv_max_output = f;
     }
 };
 struct ChromaV {
@@ -1272,18 +1276,26 @@ struct ChromaV {
         ch_spill_saturation, ch_soft_range, ch_inv_soft;
     uint32_t flags;
     explicit DEV ChromaV(const KOp& o)
-        : ch_target_hue(in_vgpr(o.ch_target_hue)), ch_hue_width(in_vgpr(o.ch_hue_width)),
-          ch_min_saturation(in_vgpr(o.ch_min_saturation)), ch_min_brightness(in_vgpr(o.ch_min_brightness)),
-          ch_spill(in_vgpr(o.ch_spill)), ch_inv_spill(in_vgpr(o.ch_inv_spill)),
-          ch_spill_saturation(in_vgpr(o.ch_spill_saturation)), ch_soft_range(in_vgpr(o.ch_soft_range)),
-          ch_inv_soft(in_vgpr(o.ch_inv_soft)), flags(o.flags)
-    {
+        : flags(o.flags)
+    { /* one batch of scalar loads and one wait (see ycoef16) */
+        float a = o.ch_target_hue, b = o.ch_hue_width, c = o.ch_min_saturation, d = o.ch_min_brightness, e = o.ch_spill,
+              f = o.ch_inv_spill, g = o.ch_spill_saturation, h = o.ch_soft_range, i = o.ch_inv_soft;
+        asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(e), "+s"(f), "+s"(g), "+s"(h), "+s"(i));
+        ch_target_hue = in_vgpr(a), ch_hue_width = in_vgpr(b), ch_min_saturation = in_vgpr(c);
+        ch_min_brightness = in_vgpr(d), ch_spill = in_vgpr(e), ch_inv_spill = in_vgpr(f);
+        ch_spill_saturation = in_vgpr(g), ch_soft_range = in_vgpr(h), ch_inv_soft = in_vgpr(i);
     }
 };
 struct CsbV {
     float    brt, sat, con;
     uint32_t flags;
-    explicit DEV CsbV(const KOp& o) : brt(in_vgpr(o.brt)), sat(in_vgpr(o.sat)), con(in_vgpr(o.con)), flags(o.flags) {}
+    explicit DEV CsbV(const KOp& o)
+        : flags(o.flags)
+    {
+        float a = o.brt, b = o.sat, c = o.con;
+        asm volatile("" : "+s"(a), "+s"(b), "+s"(c));
+        brt = in_vgpr(a), sat = in_vgpr(b), con = in_vgpr(c);
+    }
 };
 
 /* ------------------------------------------------------------------ the fast compositor */
@@ -1559,8 +1571,13 @@ struct YCoef {
 };
 DEV YCoef ycoef16(const KOp& o) /* from the planner (cghip_plan.cpp: classify_fast), moved to VGPRs once per op */
 {
-    return YCoef{in_vgpr(o.ycoef[0]), in_vgpr(o.ycoef[1]), in_vgpr(o.ycoef[2]), in_vgpr(o.ycoef[3]),
-                 in_vgpr(o.ycoef[4]), in_vgpr(o.ycoef[5]), in_vgpr(o.ycoef[6]), in_vgpr(o.ycoef[7])};
+    /* all eight pinned in SGPRs first, so that they arrive in ONE scalar load and one wait: with in_vgpr() straight on
+       the fields every coefficient was a load, a wait and a move of its own, eight scalar-cache round trips in a row
+       per op and wave */
+    float k0 = o.ycoef[0], k1 = o.ycoef[1], k2 = o.ycoef[2], k3 = o.ycoef[3], k4 = o.ycoef[4], k5 = o.ycoef[5],
+          k6 = o.ycoef[6], k7 = o.ycoef[7];
+    asm volatile("" : "+s"(k0), "+s"(k1), "+s"(k2), "+s"(k3), "+s"(k4), "+s"(k5), "+s"(k6), "+s"(k7));
+    return YCoef{in_vgpr(k0), in_vgpr(k1), in_vgpr(k2), in_vgpr(k3), in_vgpr(k4), in_vgpr(k5), in_vgpr(k6), in_vgpr(k7)};
 }
 /* four chroma CODES (not normalised) of one plane row for a lane's pixels */
 template <int HX>
@@ -1608,6 +1625,8 @@ DEV Row3 load_chroma16(uint64_t ptr, int w, int row, int sx, const ChromaOff o)
     }
     return v;
 }
+/* a value nobody looks at: the compiler may leave whatever the register holds (no instruction) */
+DEV float dont_care() { return __builtin_nondeterministic_value(0.0f); }
 template <int HX, int HY>
 DEV void fetch_planar16r(const KOp& kop, const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
 {
@@ -1620,44 +1639,56 @@ DEV void fetch_planar16r(const KOp& kop, const HotOp& op, int sx, int sy, bool r
         const int k = sx >> 1;
         co.a = (uint32_t)k * 2u, co.l = (uint32_t)imax(k - 1, 0) * 2u, co.r = (uint32_t)imin(k + 2, op.w1 - 1) * 2u;
     }
-    /* all loads first */
-    const u32x2 yv  = load_at<u32x2>(row_base(op.ptr0, sy, op.w0, 2u), (uint32_t)sx * 2u);
-    const Row3  cr0 = load_chroma16<HX>(op.ptr2, op.w1, ra, sx, co);
-    Row3        cb0 = {0, 0, 0}, cb1 = {0, 0, 0}, cr1 = {0, 0, 0};
-    u32x2       av  = {0, 0};
-    if (HY)
-        cr1 = load_chroma16<HX>(op.ptr2, op.w1, rb, sx, co);
-    if (!red_only) {
-        cb0 = load_chroma16<HX>(op.ptr1, op.w1, ra, sx, co);
+    /* Two straight-line variants, picked by the wave-uniform red_only: a key draw without colour adjustments (only red
+       and alpha are ever looked at, image_mixer.cpp:174-183: no Cb plane, no green, no blue) and the full colour. As ONE
+       body with `if (!red_only)` around the Cb loads and the green / blue rows, every value those ifs define needed a
+       default: 23 v_mov per op and lane in front of the branches, a tenth of a plain layer's instructions. Each
+       variant issues all its loads first (the full one starts with the Cb rows, so that the two do not begin alike:
+       the compiler hoists a common beginning in front of the branch, waits for those loads there, and the Cb rows
+       became a second round trip). */
+    if (red_only) {
+        const u32x2 yv  = load_at<u32x2>(row_base(op.ptr0, sy, op.w0, 2u), (uint32_t)sx * 2u);
+        const Row3  cr0 = load_chroma16<HX>(op.ptr2, op.w1, ra, sx, co);
+        Row3        cr1 = {0, 0, 0};
         if (HY)
-            cb1 = load_chroma16<HX>(op.ptr1, op.w1, rb, sx, co);
-    }
-    if (alpha)
-        av = load_at<u32x2>(row_base(op.ptr3, sy, op.w0, 2u), (uint32_t)sx * 2u);
-
-    const YCoef k = ycoef16(kop);
-    const float Y[4] = {(float)(yv.x & 0xffff), (float)(yv.x >> 16), (float)(yv.y & 0xffff), (float)(yv.y >> 16)};
-    float       Cr[4], Cb[4] = {0, 0, 0, 0};
-    chroma_codes<HX, HY>(cr0, cr1, sy, Cr);
-    if (!red_only)
-        chroma_codes<HX, HY>(cb0, cb1, sy, Cb);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        col[i].z = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cr[i], k.aR, k.cR));
-        col[i].w = 1.0f;
-        col[i].x = col[i].y = 0.0f;
-    }
-    if (alpha) { /* wave-uniform; the empty asm keeps it a branch (as selects every draw paid 12 instructions for it) */
-        asm volatile("");
-        col[0].w = (float)(av.x & 0xffff) * (1.0f / 65535.0f), col[1].w = (float)(av.x >> 16) * (1.0f / 65535.0f);
-        col[2].w = (float)(av.y & 0xffff) * (1.0f / 65535.0f), col[3].w = (float)(av.y >> 16) * (1.0f / 65535.0f);
-    }
-    if (!red_only) {
+            cr1 = load_chroma16<HX>(op.ptr2, op.w1, rb, sx, co);
+        const YCoef k = ycoef16(kop);
+        const float Y[4] = {(float)(yv.x & 0xffff), (float)(yv.x >> 16), (float)(yv.y & 0xffff), (float)(yv.y >> 16)};
+        float       Cr[4];
+        chroma_codes<HX, HY>(cr0, cr1, sy, Cr);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            col[i].z = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cr[i], k.aR, k.cR));
+            col[i].w = 1.0f;
+            col[i].x = col[i].y = dont_care();
+        }
+    } else {
+        const Row3 cb0 = load_chroma16<HX>(op.ptr1, op.w1, ra, sx, co);
+        Row3       cb1 = {0, 0, 0}, cr1 = {0, 0, 0};
+        if (HY)
+            cb1 = load_chroma16<HX>(op.ptr1, op.w1, rb, sx, co);
+        const Row3  cr0 = load_chroma16<HX>(op.ptr2, op.w1, ra, sx, co);
+        if (HY)
+            cr1 = load_chroma16<HX>(op.ptr2, op.w1, rb, sx, co);
+        const u32x2 yv  = load_at<u32x2>(row_base(op.ptr0, sy, op.w0, 2u), (uint32_t)sx * 2u);
+        const YCoef k = ycoef16(kop);
+        const float Y[4] = {(float)(yv.x & 0xffff), (float)(yv.x >> 16), (float)(yv.y & 0xffff), (float)(yv.y >> 16)};
+        float       Cr[4], Cb[4];
+        chroma_codes<HX, HY>(cr0, cr1, sy, Cr);
+        chroma_codes<HX, HY>(cb0, cb1, sy, Cb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            col[i].z = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cr[i], k.aR, k.cR));
             col[i].y = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cr[i], k.aGr, __builtin_fmaf(Cb[i], k.aGb, k.cG)));
             col[i].x = __builtin_fmaf(Y[i], k.aY, __builtin_fmaf(Cb[i], k.aB, k.cB));
+            col[i].w = 1.0f;
         }
+    }
+    if (alpha) { /* wave-uniform and rare (ycbcra): a round trip of its own; the empty asm keeps it a branch */
+        asm volatile("");
+        const u32x2 av = load_at<u32x2>(row_base(op.ptr3, sy, op.w0, 2u), (uint32_t)sx * 2u);
+        col[0].w = (float)(av.x & 0xffff) * (1.0f / 65535.0f), col[1].w = (float)(av.x >> 16) * (1.0f / 65535.0f);
+        col[2].w = (float)(av.y & 0xffff) * (1.0f / 65535.0f), col[3].w = (float)(av.y >> 16) * (1.0f / 65535.0f);
     }
 }
 
@@ -2139,10 +2170,13 @@ DEV void fetch_rect16(const KOp& op, const HotG& g, int ax0, int ax1, int px0, i
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
-template <int BITS, bool FULL, int EXT, bool ONE = false> /* EXT: 0 aligned bodies only, 1 + sampled boxes, 2 + fused
-                                                            blend-mode layers. ONE (with FULL): the launch never touches
-                                                            RGBA2 - a MIX transition outside blend-mode layers - and
-                                                            the kernel does not hold it: 16 registers less per lane */
+template <int BITS, bool FULL, int EXT, bool ONE = false, int MONO = -1> /* EXT: 0 aligned bodies only, 1 + sampled boxes,
+                                                            2 + fused blend-mode layers. ONE (with FULL): the launch never
+                                                            touches RGBA2 - a MIX transition outside blend-mode layers -
+                                                            and the kernel does not hold it: 16 registers less per lane.
+                                                            MONO >= 0: every draw of the launch takes THIS fetch body (a
+                                                            stack of sources of one format, KSpill::mono): the switch
+                                                            over the bodies folds away, see cghip_composite_fast_m */
 DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, const KSpill& sp)
 {
     constexpr int  P       = 4;
@@ -2223,7 +2257,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
         fetch_planar16r<HX, HY>(op, h, sx, SY, red_only, col);                                                         \
     else                                                                                                               \
         fetch_planar<16, HX, HY>(h, sx, SY, red_only, col);
-        switch (h.fetch_body) {
+        switch (MONO >= 0 ? MONO : h.fetch_body) {
             case FB_SURFACE:
                 if constexpr (FULL) {
                     if constexpr (ONE) {
@@ -2342,10 +2376,17 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                     tex[i] = f4{quantize<BITS>(fo.f[i].x), quantize<BITS>(fo.f[i].y), quantize<BITS>(fo.f[i].z), quantize<BITS>(fo.f[i].w)};
                 });
                 shade_blend_mode4<BITS>(BlendArgs{op.b_flags, op.b_local_key, op.b_layer_key, op.b_opacity, op.b_blend_mode}, tex, S, K0, K1);
-            } else if (h.dst >= KS_KEY0)
-                store_key4<BITS>(fo, h.dst == KS_KEY1, K0, K1);
-            else
-                store_rgba4<BITS>(fo, S);
+            } else {
+                /* Two ifs, not if / else, and the second test opaque: the compiler structurizes uniform branches too, and
+                   an if / else gets a never-taken edge from its `then` to its `else` block. Across that edge the frame
+                   registers a key draw leaves alone stay live through the colour draw's block, so the colour draw could
+                   not update them where they live: sixteen results in temporaries, sixteen copies at the loop latch per
+                   op and lane (8 % of a plain layer's instructions). Two triangles have no such edge. */
+                if (h.dst >= KS_KEY0)
+                    store_key4<BITS>(fo, h.dst == KS_KEY1, K0, K1);
+                if (opaque_s(h.dst) < KS_KEY0)
+                    store_rgba4<BITS>(fo, S);
+            }
         } else {
             /* With the two temporaries the kernel sits at its 128-register bound: carrying the fore colour of four
                pixels across a merge spilled (config 4: 0.025 -> 0.042 ms), so here every variant rewrites its surface
@@ -2469,6 +2510,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONE_TEMP_WA
 {
     composite_fast_body<BITS, true, 0, true>(ops, nops, out, W, H, field_mode, sp);
 }
+/* Stacks of ONE source format - what a channel fed by one kind of input composites: 4:2:2 video layers with their
+ * keys, an SDI rundown of uyvy inputs, stills and graphics in bgra. Every draw of such a launch takes the same fetch
+ * body (KSpill::mono, cghip_plan.cpp), and an instance of the lean kernel compiled for that body alone has no switch
+ * over twenty bodies in its op loop: fewer paths meet at the loop latch (fewer register copies there), less scalar
+ * set-up per op. The instances below are the formats the BASELINE configs and live inputs use; anything else runs the
+ * kernel with all bodies, as before. Same arithmetic, same code: the body is a template argument. */
+#ifndef MONO_WAVES
+#define MONO_WAVES LEAN_WAVES
+#endif
+template <int BITS, int MONO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MONO_WAVES))) void cghip_composite_fast_m(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, false, 0, false, MONO>(ops, nops, out, W, H, field_mode, sp);
+}
 /* The same two with the sampled fetch bodies (FB_RECT8) compiled in, for launches that hold such a draw.
  * Kernels of their own: with those bodies in it the kernel of full-screen stacks allocated its registers differently
  * and the headline frame went from 0.207 to 0.284 ms. */
@@ -2545,12 +2601,15 @@ constexpr unsigned XCD_MIN_TILES = 4096; /* 1080p is 2160 tiles of the 4-pixels-
 int      cghip_g_plain_tiles = 0;
 int      cghip_g_pad_lds     = 0;
 unsigned cghip_g_fast_rows   = 4;
+int      cghip_g_no_mono     = 0;
 extern "C" void cghip_debug_plain_tiles(int on) { cghip_g_plain_tiles = on; } /* tiles in dispatch order */
+extern "C" void cghip_debug_no_mono_kernels(int on) { cghip_g_no_mono = on; } /* one-format stacks run the kernel with all bodies */
 extern "C" void cghip_debug_fast_rows(int rows) { cghip_g_fast_rows = rows >= 1 && rows <= 4 ? (unsigned)rows : 4u; }
 /* occupancy experiments: dynamic LDS nobody touches, to cap the workgroups resident on a CU (160 KB per CU) */
 extern "C" void cghip_debug_pad_lds(int bytes) { cghip_g_pad_lds = bytes; }
 #else
 extern int      cghip_g_plain_tiles;
+extern int      cghip_g_no_mono;
 extern int      cghip_g_pad_lds;
 extern unsigned cghip_g_fast_rows;
 #endif
@@ -2590,6 +2649,26 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
         const unsigned nbx = (unsigned)((gw + 255) / 256), nby = (unsigned)((gh + rows - 1) / rows);
         const dim3     grid = tiles(nbx, nby, nbx * nby >= XCD_MIN_TILES && !cghip_g_plain_tiles);
         const bool sampled = fast >= 2; /* the launch holds a draw with a sampled fetch body (2) or a fused layer (3) */
+#define LAUNCH_MONO(body)                                                                                              \
+    hipLaunchKernelGGL((cghip_composite_fast_m<FB, body>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s)
+        const int mono = (!full && !sampled && !cghip_g_no_mono) ? s.mono : -1;
+        bool      launched = true; /* the instances of this object's frame depth only; measured on the same box against
+                                      the kernel with all bodies (tests/gpu_ab.sh): packed 8-bit stacks -7 % (config 1
+                                      -5 %), 4:2:2 16-bit stacks -1 .. -3 %. 8-bit planar and 16-bit packed instances
+                                      measured 0 .. +3 % (their registers were allocated no better) and do not exist. */
+        if constexpr (FB == 16) {
+            if (mono == FB_PLANAR16 + 1)
+                LAUNCH_MONO(FB_PLANAR16 + 1);
+            else
+                launched = false;
+        } else {
+            if (mono == FB_PACKED8)
+                LAUNCH_MONO(FB_PACKED8);
+            else
+                launched = false;
+        }
+        if (launched)
+            return hipGetLastError();
         if (!full && fast == 3)
             hipLaunchKernelGGL((cghip_composite_fast_x<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!full && !sampled)

@@ -773,6 +773,17 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             if (o.kind == KOP_DRAW_PLANES)
                 sg.ext = std::max(sg.ext, o.fused ? 2 : (o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END) ? 1 : 0);
         }
+        sg.mono = -1; /* one source format throughout: the kernel instance compiled for that fetch body alone */
+        if (sg.fast && !sg.full && sg.ext == 0) {
+            int body = -2;
+            for (int i = sg.first; i < sg.first + sg.count; ++i) {
+                const KOp& o = ops[(size_t)i];
+                if (o.kind == KOP_CLEAR)
+                    continue;
+                body = (body == -2 || body == o.fetch_body) ? o.fetch_body : -1;
+            }
+            sg.mono = body >= 0 ? body : -1;
+        }
         sg.load_mask  = touched & in_mem;
         sg.store_mask = written & ~zero & later;
         if (si == 0)
