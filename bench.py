@@ -133,12 +133,14 @@ class Channel:
         self.mixer.close()
 
 
-def run_steps(ch, steps, in_flight=2):
+def run_steps(ch, steps, in_flight=2, readback=False):
     """Issue `steps` frames keeping `in_flight` in the pipeline (the reference keeps 1-2, mixer.cpp:75-91).
-    Returns the list of per-frame kernel durations (ms, hipEvents on the channel's compute stream)."""
+    Returns the list of per-frame kernel durations (ms, hipEvents on the channel's compute stream). readback: every
+    frame is copied to pinned host memory on the channel's readback stream (device::copy_async(texture),
+    device.cpp:264-302); the host-side copy out of the pinned buffer is the consumer's business and not made."""
     pend, kernel_ms = [], []
     for _ in range(steps):
-        pend.append(ch.submit(readback=False))
+        pend.append(ch.submit(readback=readback))
         if len(pend) > in_flight:
             ch.mixer.get(pend.pop(0), want_output=False)
             kernel_ms.append(ch.mixer.last_kernel_ms)
@@ -216,19 +218,67 @@ def cpu_baseline(S, scene, budget_s=12.0):
 SETTLE_S = 5.0
 
 
+def native_topology(args):
+    """BASELINE configs[3] / configs[4] in the product's own topology - ONE process, N GPUs, a native thread per
+    channel, routed frames copied GPU to GPU over xGMI (tests/native/route_driver.cpp) - as a child process started
+    BEFORE this one touches the GPU. One JSON line in bench.py's format; `value` is the aggregate frames/s."""
+    import subprocess
+    rank = int(os.environ.get("RANK", "0"))
+    if rank != 0:  # under torch.distributed.run: the driver is one process for the whole node, rank 0 starts it
+        return
+    exe = os.path.join(ROOT, "tests", "native", "route_driver")
+    if not os.path.exists(exe):
+        raise SystemExit("tests/native/route_driver is missing: run __graft_entry__.build()")
+    wl = "config5" if args.workload == "config5" else "config4"
+    cmd = [exe, "--workload", wl, "--gpus", str(args.gpus), "--frames", str(args.steps)]
+    if args.channels_per_gpu > 1 or wl == "config4":
+        per_gpu = args.channels_per_gpu if args.channels_per_gpu > 1 else max(1, 32 // args.gpus)
+        cmd += ["--channels", str(per_gpu * args.gpus)]
+    if args.stand_in:
+        cmd.append("--stand-in")
+    if args.readback:
+        cmd.append("--readback")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise SystemExit("route_driver failed (%d): %s" % (r.returncode, (r.stderr or r.stdout)[-800:]))
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    line = {
+        "metric": "aggregate composited frames/s, %s (%d channels over %d GPU(s), one process)" % (wl, d["channels"], d["gpus"]),
+        "value": d["frames_per_s"], "unit": "frames/s", "n_gpus": d["gpus"], "steps": args.steps, "warmup": 10 if wl == "config5" else 50,
+        "ms_per_step": 1e3 / d["per_channel_fps"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": d["workload"], "channels": d["channels"], "topology": d["topology"],
+                   "route_ring": d["route_ring"], "stand_in_devices": d["stand_in_devices"], "readback": d["readback"]},
+        "peer_copy_GBps": d["peer_copy_GBps"], "peer_copies": d["peer_copies"], "peer_copy_bytes": d["peer_copy_bytes"],
+        "peer_access": d["peer_access"], "per_gpu_fps": d["per_gpu_fps"], "per_channel_fps": d["per_channel_fps"],
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="config3_16bit", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config3_16bit", choices=sorted(WORKLOADS) + ["config5", "config4_native"],
+                    help="config5 / config4_native: one process, N GPUs, a native thread per channel, routes over xGMI "
+                         "(tests/native/route_driver.cpp); the others: one channel (or --channels-per-gpu) per rank")
+    ap.add_argument("--stand-in", action="store_true",
+                    help="config5 / config4_native on a box with fewer GPUs than --gpus: the missing GPUs are private device "
+                         "objects on GPU 0 (the whole routed path runs, over one GPU's memory)")
     ap.add_argument("--channels-per-gpu", type=int, default=1,
                     help="channels each rank drives on its GPU, one stream each (configs[3]: 32 channels over N GPUs)")
     ap.add_argument("--settle", type=float, default=SETTLE_S,
                     help="seconds of untimed load before the warmup steps (counter-collection passes use a short one)")
+    ap.add_argument("--readback", action="store_true",
+                    help="after the timed region, a second one of the same length with every frame read back to pinned "
+                         "host memory on the channel's readback stream; reported as `readback`, never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
+    if args.workload in ("config5", "config4_native"):
+        return native_topology(args)  # a child process, started before anything here initialises the GPU
 
     rank, world, local_rank, barrier, allreduce_max = dist_setup(args.gpus)
     import scenes as S
@@ -281,6 +331,22 @@ def main():
         # launches of different channels overlap on the GPU, so a launch's own duration says little: price the GPU's
         # algorithmic bytes over the timed region instead
         achieved = alg_bytes * ncha * args.steps / dt / 1e9
+
+    rb = None
+    if args.readback and ncha == 1:
+        # resident sources, every frame read back: the channel as the reference runs it (the adapter always reads
+        # back). Kernel and D2H overlap on two streams, so the rate to expect is min(kernel rate, D2H rate).
+        run_steps(chs[0], max(4, args.warmup), readback=True)
+        device_sync()
+        tr0 = time.perf_counter()
+        rb_kernel_ms = run_steps(chs[0], args.steps, readback=True)
+        device_sync()
+        rdt = time.perf_counter() - tr0
+        frame_bytes = scene["width"] * scene["height"] * 4 * (scene["bits"] // 8)
+        rb = {"frames_per_s": args.steps / rdt, "ms_per_step": rdt / args.steps * 1e3,
+              "avg_kernel_ms": sum(rb_kernel_ms) / len(rb_kernel_ms), "frame_bytes": frame_bytes,
+              "d2h_GBps": frame_bytes * args.steps / rdt / 1e9,
+              "note": "sources resident, frame read back to pinned memory every step on the readback stream; 2 in flight"}
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
@@ -337,6 +403,8 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end_fps": e2e,
         }
+        if rb is not None:
+            line["readback"] = rb
         print(json.dumps(line), flush=True)
 
     if world > 1 or os.environ.get("CGHIP_DIST_FORCE_GROUP"):

@@ -189,6 +189,21 @@ int cghost_mixer_create(int channel_id, int gpu_index, void** out)
     });
 }
 
+/* Another channel on the device object `other` renders on (the accelerator's shared one or a private stand-in): how N
+ * channels share one stand-in "GPU" in tests/native/route_driver.cpp. */
+int cghost_mixer_create_on(void* other, int channel_id, void** out)
+{
+    return guarded([&] {
+        auto* o = static_cast<host_mixer*>(other);
+        if (!o || !o->dev)
+            throw invalid_argument("mixer has no device");
+        auto hm   = std::make_unique<host_mixer>();
+        hm->dev   = o->dev;
+        hm->mixer = std::make_unique<hip::image_mixer>(hm->dev, channel_id);
+        *out      = hm.release();
+    });
+}
+
 int cghost_mixer_destroy(void* h)
 {
     delete static_cast<host_mixer*>(h);

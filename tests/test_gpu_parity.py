@@ -570,3 +570,29 @@ def test_native_channel_threads_with_frame_churn():
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
     lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
     assert lines[0]["channels"] == 8 and lines[-1] == {"churn": 1, "channels_with_a_changed_frame": 0}
+
+
+@pytest.mark.gpu
+def test_route_driver_config5_ring_with_stand_in_devices():
+    """BASELINE configs[4] in the product's topology (tests/native/route_driver.cpp: one process, N GPUs, a native thread
+    per channel; `bench.py --workload config5`): on the one-GPU box the second GPU is a private device object, so every
+    channel's routed layer 0 - made anew each tick by the neighbour GPU's producer - is peer-copied (three planes of a
+    4:2:2 frame) exactly once per channel and frame, and nothing of those frames outlives them."""
+    import json, os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "route_driver")
+    assert os.path.exists(exe), "tests/native/route_driver is missing: run __graft_entry__.build()"
+    W, H, C, F = 960, 540, 4, 12
+    r = subprocess.run([exe, "--workload", "config5", "--gpus", "2", "--stand-in", "--channels", str(C), "--frames", str(F),
+                        "--width", str(W), "--height", str(H)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["gpus"] == 2 and d["stand_in_devices"] == 1 and d["route_ring"] == 1 and d["channels"] == C
+    assert d["peer_copies"] == C * F * 3, d
+    assert d["peer_copy_bytes"] == C * F * W * H * 2, d
+    assert d["frames_per_s"] > 0 and d["peer_copy_GBps"] > 0
+    # config 4 (32 MIX-transition channels) through the same driver, no routes
+    r = subprocess.run([exe, "--workload", "config4", "--gpus", "1", "--channels", "8", "--frames", "40", "--width", "640",
+                        "--height", "360"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["channels"] == 8 and d["peer_copies"] == 0 and d["frames_per_s"] > 0
