@@ -18,8 +18,9 @@ int cghip_debug_plan(const cghip_format* fmt, const cghip_surface* surfaces, int
 int cghip_debug_kop_size(void);
 /* In *full above: bit 0 = the frame uses RGBA temporaries, bit 1 = every draw is of the 4-pixels-per-lane class,
  * bits 8.. = number of kernel launches (segments) the frame is cut into.
- * The launches of a planned frame, 10 ints each: first op, op count, fast, full, load mask, store mask, and the pixel
- * box gx0, gy0, gx1, gy1 the launch covers. Returns the number of launches (or an error < 0). */
+ * The launches of a planned frame, 14 ints each: first op, op count, fast, full, load mask, store mask, the pixel
+ * box gx0, gy0, gx1, gy1 the launch covers, and the key buffers KEY0 / KEY1 are loaded from and stored to (-1: none).
+ * Returns the number of launches (or an error < 0). */
 int cghip_debug_plan_segments(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces,
                               const cghip_draw* draws, int ndraws, int* out, int capacity);
 /* At most n launches per frame (1 = never cut a frame; default 8). */
@@ -33,6 +34,9 @@ int cghip_debug_plane_stub(int width, int height, int channels, int bits, cghip_
 /* Plans every frame as one launch of the general one-pixel-per-lane kernel, so tests can compare it with the
  * 4-pixels-per-lane kernel and with frames cut into several launches. */
 void cghip_debug_force_general_kernel(int on);
+/* The planner's KOP_SAVE_KEY / KOP_LOAD_KEY markers (a key texture leaves / re-enters a key register: frames with more
+ * than two key textures alive at once) stay in the op list cghip_debug_plan returns, so tests can replay them. */
+void cghip_debug_keep_pseudo_ops(int on);
 /* The planner shrinks the composite of a layer / mix temporary to the box that was drawn into the temporary (outside it
  * the draw is the identity); on = composites cover the whole frame as in the reference, so tests can compare. */
 void cghip_debug_full_frame_composites(int on);

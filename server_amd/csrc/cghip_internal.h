@@ -115,8 +115,10 @@ struct cghip_ticket {
     size_t                    ops_bytes = 0;
     hipEvent_t                ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr, ev_ops = nullptr;
     int                       launches = 0;
-    void*                     spill[4] = {nullptr, nullptr, nullptr, nullptr}; /* RGBA1, RGBA2, KEY0, KEY1 between launches */
-    size_t                    spill_bytes[4] = {0, 0, 0, 0};
+    void*                     spill[2] = {nullptr, nullptr}; /* RGBA1, RGBA2 between launches */
+    size_t                    spill_bytes[2] = {0, 0};
+    std::vector<void*>        key_bufs; /* key surfaces between launches (frame_plan::n_key_bufs) */
+    size_t                    key_buf_bytes = 0;
     std::vector<cghip_plane*> planes; /* retained until the frame is done */
 };
 
@@ -132,6 +134,9 @@ struct segment {
     int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
     int      mono = -1;            /* fast, not full, ext 0: the one fetch body all its draws take (KSpill::mono), else -1 */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
+    /* key buffers (frame_plan::n_key_bufs of them, W x H samples each) the launch loads KEY0 / KEY1 from and stores them
+       to, -1 = none: a key texture parked in HBM keeps its buffer while its register serves another (cghip_plan.cpp) */
+    int      key_ld[2] = {-1, -1}, key_st[2] = {-1, -1};
     int      gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0; /* pixel box the launch covers */
     /* op masks per band of the frame (KSpill::masks): offset into frame_plan::masks, in uint64 */
     size_t   mask_off = 0;
@@ -142,7 +147,8 @@ struct segment {
 struct frame_plan {
     std::vector<KOp> ops;
     std::vector<segment> segments; /* never empty: an empty scene is one launch that stores the zero frame */
-    uint32_t         spill_mask = 0; /* KSurf bits (RGBA1..KEY1) that need a buffer in HBM between launches */
+    uint32_t         spill_mask = 0; /* KSurf bits (RGBA1, RGBA2) that need a buffer in HBM between launches */
+    int              n_key_bufs = 0; /* 1-channel buffers the launches hand key surfaces over through */
     bool             full = false; /* needs the RGBA1/RGBA2 register surfaces */
     bool             fast = false; /* every draw qualifies for cghip_composite_fast (then there is one segment) */
     std::vector<cghip_plane*> planes; /* every plane referenced by an emitted op */

@@ -1236,8 +1236,8 @@ __global__ __launch_bounds__(256) void cghip_composite(const KOp* __restrict__ o
     if (sp.store_mask & (1u << KS_RGBA0)) store_px<BITS>(out, idx, s0);
     if (FULL && (sp.store_mask & (1u << KS_RGBA1))) store_px<BITS>(sp.rgba1, idx, s1);
     if (FULL && (sp.store_mask & (1u << KS_RGBA2))) store_px<BITS>(sp.rgba2, idx, s2);
-    if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0, idx, k0);
-    if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1, idx, k1);
+    if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0_st, idx, k0);
+    if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1_st, idx, k1);
 }
 
 /* Adjustment parameters copied into VGPRs once per op, for the 4-pixels-per-lane kernel: a VALU instruction with an
@@ -2437,8 +2437,8 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 const size_t idx = (size_t)y * W + px0 + i;
                 if (FULL && (sp.store_mask & (1u << KS_RGBA1))) store_px<BITS>(sp.rgba1, idx, S1[i]);
                 if (FULL && !ONE && (sp.store_mask & (1u << KS_RGBA2))) store_px<BITS>(sp.rgba2, idx, S2[i]);
-                if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0, idx, K0[i]);
-                if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1, idx, K1[i]);
+                if (sp.store_mask & (1u << KS_KEY0)) store_key<BITS>(sp.key0_st, idx, K0[i]);
+                if (sp.store_mask & (1u << KS_KEY1)) store_key<BITS>(sp.key1_st, idx, K1[i]);
             }
         });
     }

@@ -16,7 +16,14 @@
 enum KOpKind : int32_t {
     KOP_CLEAR        = 0, /* surface := 0 (glClearTexImage of a fresh temporary) */
     KOP_DRAW_PLANES  = 1, /* item draw: sample source planes through the quad */
-    KOP_DRAW_SURFACE = 2  /* full-frame 1:1 draw of a temporary surface (image_mixer.cpp:207-225) */
+    KOP_DRAW_SURFACE = 2, /* full-frame 1:1 draw of a temporary surface (image_mixer.cpp:207-225) */
+    /* Planner-internal markers, never seen by a kernel (cghip_plan.cpp removes them when it cuts the frame into
+       launches). The kernels hold two key surfaces; a frame with more key textures alive at once (nested sublayers with
+       keys of their own: image_mixer.cpp:104-114,153) parks one in HBM: KOP_SAVE_KEY says that the key texture
+       `src_surface` (a surface SLOT of the draw list) leaves register `dst` here - the launch in front of the marker
+       stores it -, KOP_LOAD_KEY that it returns into register `dst` - the launch behind the marker loads it. */
+    KOP_SAVE_KEY = 3,
+    KOP_LOAD_KEY = 4
 };
 
 enum KOpFlags : uint32_t {
@@ -105,8 +112,10 @@ enum KSurf : int32_t {
 struct KSpill {
     void*    rgba1;
     void*    rgba2;
-    void*    key0;
+    void*    key0; /* what KEY0 / KEY1 are LOADED from ... */
     void*    key1;
+    void*    key0_st; /* ... and STORED to: key textures parked in HBM keep their buffer while the register moves on */
+    void*    key1_st;
     uint32_t load_mask;  /* surfaces to read before the first op */
     uint32_t store_mask; /* surfaces to write after the last op */
     int32_t  gx0, gy0;

@@ -573,6 +573,8 @@ static int resolve_draw(const cghip_format& fmt, const cghip_draw& d, KOp& op)
  * looping background under a full-screen clip, say - and so is every key or temporary only such draws consumed. The
  * GL mixer draws it all; here a backward liveness pass over the op list drops it. */
 static int g_keep_hidden_ops = 0; /* test hook */
+static bool is_pseudo(const KOp& o);
+static bool is_marker(const KOp& o);
 
 static bool replaces_frame(const KOp& o, const cghip_format& fmt)
 {
@@ -594,6 +596,16 @@ static void drop_hidden_ops(const cghip_format& fmt, frame_plan* out)
     for (size_t i = ops.size(); i-- > 0;) {
         const KOp&     o   = ops[i];
         const uint32_t dst = o.dst >= 0 && o.dst < KS_COUNT ? 1u << o.dst : 0u;
+        if (o.kind == KOP_SAVE_KEY) { /* never dropped (its LOAD may be kept): the register's value matters here */
+            keep[i] = 1;
+            live |= dst;
+            continue;
+        }
+        if (o.kind == KOP_LOAD_KEY) { /* rewrites its register: what was there before is dead */
+            keep[i] = 1;
+            live &= ~dst;
+            continue;
+        }
         if (!(live & dst)) {
             any_dropped = true;
             continue;
@@ -621,7 +633,7 @@ static void drop_hidden_ops(const cghip_format& fmt, frame_plan* out)
     for (const KOp& o : ops) {
         if (o.dst == KS_RGBA1 || o.dst == KS_RGBA2)
             out->full = true;
-        if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
+        if (!is_marker(o) && o.fast_class == FC_NONE)
             out->fast = false;
     }
 }
@@ -634,13 +646,16 @@ static void drop_hidden_ops(const cghip_format& fmt, frame_plan* out)
  * full-screen draw moved from the general kernel to the fast one: a two-state shortest path over the op list decides
  * where cutting pays. */
 static int g_force_general = 0;
+static int g_keep_pseudo_ops = 0; /* test hook: KOP_SAVE_KEY / KOP_LOAD_KEY stay in the op list that cghip_debug_plan returns */
 static int g_max_segments  = 8;
 static double g_cut_scale  = 1.0;
 
 static uint32_t surf_bit(int s) { return s >= 0 && s < KS_COUNT ? 1u << s : 0u; }
+static bool     is_pseudo(const KOp& o) { return o.kind == KOP_SAVE_KEY || o.kind == KOP_LOAD_KEY; }
+static bool     is_marker(const KOp& o) { return o.kind == KOP_CLEAR || is_pseudo(o); } /* no pixels of its own */
 static uint32_t refs_of(const KOp& o) /* surfaces an op reads or writes */
 {
-    if (o.kind == KOP_CLEAR)
+    if (is_marker(o)) /* CLEAR / LOAD_KEY rewrite their register, SAVE_KEY reads it */
         return surf_bit(o.dst);
     return surf_bit(o.dst) | surf_bit(o.local_key) | surf_bit(o.layer_key) |
            (o.kind == KOP_DRAW_SURFACE ? surf_bit(o.src_surface) : 0u) |
@@ -690,7 +705,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         std::vector<uint8_t> from((size_t)(n + 1) * 2, 0);
         cost[0] = cost[1] = 0.0;
         auto box_area = [&](int i) { /* a CLEAR in front of a draw is priced as that draw when it opens a run */
-            while (i < n && ops[(size_t)i].kind == KOP_CLEAR)
+            while (i < n && is_marker(ops[(size_t)i]))
                 ++i;
             return i < n ? (double)std::max(0, ops[(size_t)i].x1 - ops[(size_t)i].x0) *
                                std::max(0, ops[(size_t)i].y1 - ops[(size_t)i].y0)
@@ -698,7 +713,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         };
         for (int i = 0; i < n; ++i) {
             const KOp&   o    = ops[(size_t)i];
-            const bool   clr  = o.kind == KOP_CLEAR;
+            const bool   clr  = is_marker(o);
             const double area = clr ? 0.0 : box_area(i), open_area = box_area(i);
             for (int k = 0; k < 2; ++k) {
                 if (k == 1 && !clr && o.fast_class == FC_NONE)
@@ -724,13 +739,27 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             std::fill(cls.begin(), cls.end(), (uint8_t)0);
     }
 
-    /* 2. runs of one class */
+    for (int i = n - 2; i >= 0; --i) /* a marker runs with the draw it stands in front of */
+        if (is_marker(ops[(size_t)i]))
+            cls[(size_t)i] = cls[(size_t)i + 1];
+    /* 2. runs of one class. A key texture that leaves or re-enters a register (KOP_SAVE_KEY / KOP_LOAD_KEY: more than
+       two key textures alive at once) forces a cut in front of the group of markers it stands in: the launch before the
+       cut stores the register, the launch behind it loads the register. */
+    std::vector<uint8_t> forced((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i)
+        if (is_pseudo(ops[(size_t)i])) {
+            int g = i;
+            while (g > 0 && is_marker(ops[(size_t)g - 1]))
+                --g;
+            forced[(size_t)g] = 1;
+        }
     for (int i = 0; i < n;) {
         segment sg;
         sg.first = i;
         sg.fast  = cls[(size_t)i] != 0;
-        while (i < n && (cls[(size_t)i] != 0) == sg.fast)
+        do
             ++i;
+        while (i < n && (cls[(size_t)i] != 0) == sg.fast && !forced[(size_t)i]);
         sg.count = i - sg.first;
         out->segments.push_back(sg);
     }
@@ -741,14 +770,59 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
     }
 
     /* 3. which surfaces cross the cuts. in_mem: the HBM copy is the current value; a surface whose last write in a
-       segment is a CLEAR is zero, and zero is what a launch's registers start from, so it needs no copy. */
+       segment is a CLEAR is zero, and zero is what a launch's registers start from, so it needs no copy. The RGBA
+       temporaries have a buffer each; KEY0 / KEY1 take theirs from a small set (key_bufs): a key texture parked in HBM
+       (KOP_SAVE_KEY) keeps the buffer it was stored in while its register serves another texture. */
+    const uint32_t KEYS = surf_bit(KS_KEY0) | surf_bit(KS_KEY1);
     const size_t nseg   = out->segments.size();
     uint32_t     in_mem = 0;
+    int          key_buf_of[2] = {-1, -1};         /* buffer holding the register's current value, if in_mem says so */
+    std::vector<int>    home;                      /* surface slot -> buffer of its parked key texture (-2: it is zero) */
+    std::vector<uint8_t> buf_used;                 /* buffer ids in use */
+    auto buf_alloc = [&]() {
+        for (size_t b = 0; b < buf_used.size(); ++b)
+            if (!buf_used[b]) {
+                buf_used[b] = 1;
+                return (int)b;
+            }
+        buf_used.push_back(1);
+        return (int)buf_used.size() - 1;
+    };
+    auto buf_free = [&](int b) {
+        if (b >= 0)
+            buf_used[(size_t)b] = 0;
+    };
+    auto home_of = [&](int slot) -> int& {
+        if ((size_t)slot >= home.size())
+            home.resize((size_t)slot + 1, -1);
+        return home[(size_t)slot];
+    };
     for (size_t si = 0; si < nseg; ++si) {
         segment& sg      = out->segments[si];
         uint32_t touched = 0, written = 0, zero = 0, later = surf_bit(KS_RGBA0);
+        /* key textures that re-enter a register at the head of this launch */
+        for (int i = sg.first; i < sg.first + sg.count && is_marker(ops[(size_t)i]); ++i) {
+            const KOp& o = ops[(size_t)i];
+            if (o.kind != KOP_LOAD_KEY)
+                continue;
+            const int r = o.dst - KS_KEY0, b = home_of(o.src_surface);
+            if (in_mem & surf_bit(o.dst)) /* what the register held is dead (it was saved or is not needed) */
+                buf_free(key_buf_of[r]);
+            in_mem &= ~surf_bit(o.dst);
+            key_buf_of[r] = -1;
+            if (b >= 0) {
+                in_mem |= surf_bit(o.dst);
+                key_buf_of[r] = b;
+            }
+            home_of(o.src_surface) = -1;
+        }
         for (int i = sg.first; i < sg.first + sg.count; ++i) {
             const KOp& o = ops[(size_t)i];
+            if (is_pseudo(o)) { /* SAVE belongs to the launch before, LOAD was dealt with: the register counts as read */
+                if (o.kind == KOP_LOAD_KEY)
+                    touched |= surf_bit(o.dst);
+                continue;
+            }
             touched |= refs_of(o);
             written |= surf_bit(o.dst);
             if (o.kind == KOP_CLEAR)
@@ -758,10 +832,11 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         }
         uint32_t reset = 0; /* surfaces a later launch clears before anything looks at them: dead at this cut */
         for (int i = sg.first + sg.count; i < n; ++i) {
-            if (ops[(size_t)i].kind == KOP_CLEAR)
-                reset |= surf_bit(ops[(size_t)i].dst) & ~later;
+            const KOp& o = ops[(size_t)i];
+            if (o.kind == KOP_CLEAR || o.kind == KOP_LOAD_KEY)
+                reset |= surf_bit(o.dst) & ~later;
             else
-                later |= refs_of(ops[(size_t)i]) & ~reset;
+                later |= refs_of(o) & ~reset; /* a SAVE_KEY reads its register */
         }
         sg.full       = (touched & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))) != 0;
         sg.ext        = 0;
@@ -778,7 +853,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             int body = -2;
             for (int i = sg.first; i < sg.first + sg.count; ++i) {
                 const KOp& o = ops[(size_t)i];
-                if (o.kind == KOP_CLEAR)
+                if (is_marker(o))
                     continue;
                 body = (body == -2 || body == o.fetch_body) ? o.fetch_body : -1;
             }
@@ -789,8 +864,35 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         if (si == 0)
             sg.store_mask |= surf_bit(KS_RGBA0); /* the first launch defines every pixel of the frame */
         sg.one_temp = sg.full && !((touched | sg.load_mask | sg.store_mask) & surf_bit(KS_RGBA2));
+        for (int r = 0; r < 2; ++r) { /* the key registers' buffers */
+            const uint32_t bit = surf_bit(KS_KEY0 + r);
+            sg.key_ld[r] = (sg.load_mask & bit) ? key_buf_of[r] : -1;
+            if (written & bit) { /* the register's memory copy, if any, is stale */
+                buf_free(key_buf_of[r]);
+                key_buf_of[r] = -1;
+            }
+            if (sg.store_mask & bit)
+                sg.key_st[r] = key_buf_of[r] = buf_alloc();
+        }
         in_mem = (in_mem & ~written) | sg.store_mask;
-        out->spill_mask |= (sg.load_mask | sg.store_mask) & ~surf_bit(KS_RGBA0);
+        out->spill_mask |= (sg.load_mask | sg.store_mask) & ~surf_bit(KS_RGBA0) & ~KEYS;
+        /* key textures that leave their register behind this launch: they keep the buffer the value is in */
+        if (si + 1 < nseg) {
+            const segment& nx = out->segments[si + 1];
+            for (int i = nx.first; i < nx.first + nx.count && is_marker(ops[(size_t)i]); ++i) {
+                const KOp& o = ops[(size_t)i];
+                if (o.kind != KOP_SAVE_KEY)
+                    continue;
+                const int r = o.dst - KS_KEY0;
+                if (in_mem & surf_bit(o.dst)) {
+                    home_of(o.src_surface) = key_buf_of[r]; /* the buffer changes owner */
+                } else {
+                    home_of(o.src_surface) = -2; /* cleared and never drawn into: zero, which is what a load-less register is */
+                }
+                in_mem &= ~surf_bit(o.dst);
+                key_buf_of[r] = -1;
+            }
+        }
 
         /* 4. a general launch that hands nothing but the frame itself onwards only has to cover its draws */
         sg.gx0 = sg.gy0 = 0, sg.gx1 = W, sg.gy1 = H;
@@ -798,7 +900,7 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             int bx0 = W, by0 = H, bx1 = 0, by1 = 0;
             for (int i = sg.first; i < sg.first + sg.count; ++i) {
                 const KOp& o = ops[(size_t)i];
-                if (o.kind == KOP_CLEAR)
+                if (is_marker(o))
                     continue;
                 bx0 = std::min(bx0, o.x0), by0 = std::min(by0, o.y0);
                 bx1 = std::max(bx1, o.x1), by1 = std::max(by1, o.y1);
@@ -807,6 +909,25 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             bx1 = std::min(bx1, W), by1 = std::min(by1, H);
             if (bx0 < bx1 && by0 < by1)
                 sg.gx0 = bx0, sg.gy0 = by0, sg.gx1 = bx1, sg.gy1 = by1;
+        }
+    }
+    out->n_key_bufs = (int)buf_used.size();
+
+    /* 5. the markers have done their work: the kernels never see them */
+    if (!g_keep_pseudo_ops) {
+        std::vector<KOp>& mops = out->ops;
+        std::vector<int>  new_index((size_t)n + 1, 0);
+        int               m = 0;
+        for (int i = 0; i < n; ++i) {
+            new_index[(size_t)i] = m;
+            if (!is_pseudo(mops[(size_t)i]))
+                mops[(size_t)m++] = mops[(size_t)i];
+        }
+        new_index[(size_t)n] = m;
+        mops.resize((size_t)m);
+        for (segment& sg : out->segments) {
+            const int a = new_index[(size_t)sg.first], b = new_index[(size_t)(sg.first + sg.count)];
+            sg.first = a, sg.count = b - a;
         }
     }
 }
@@ -900,7 +1021,7 @@ static void fuse_layers(const cghip_format& fmt, frame_plan* out)
     for (const KOp& o : ops) {
         if (refs_of(o) & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2)))
             out->full = true;
-        if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
+        if (!is_marker(o) && o.fast_class == FC_NONE)
             out->fast = false;
     }
 }
@@ -1007,33 +1128,72 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
         o = -1;
     reg[0]          = KS_RGBA0;
     owner[KS_RGBA0] = 0;
+    std::vector<uint8_t> parked((size_t)nsurfaces, 0); /* key textures that sit in HBM (KOP_SAVE_KEY) */
+    auto marker = [&](int kind, int r, int slot) {
+        KOp c;
+        std::memset(&c, 0, sizeof c);
+        c.kind = kind, c.dst = r, c.src_surface = slot;
+        c.local_key = c.layer_key = c.b_local_key = c.b_layer_key = KS_NONE;
+        out->ops.push_back(c);
+    };
     auto bind = [&](int slot, int at) -> int {
         if (slot < 0)
             return KS_NONE;
         if (reg[(size_t)slot] != KS_NONE)
             return reg[(size_t)slot];
-        const int lo = surfaces[slot].channels == 4 ? KS_RGBA1 : KS_KEY0;
-        const int hi = surfaces[slot].channels == 4 ? KS_RGBA2 : KS_KEY1;
-        for (int r = lo; r <= hi; ++r) {
-            if (owner[r] >= 0 && last_use[(size_t)owner[r]] < at) { /* previous tenant is dead */
-                reg[(size_t)owner[r]] = KS_NONE;
-                owner[r]              = -1;
+        const bool key = surfaces[slot].channels != 4;
+        const int  lo = key ? KS_KEY0 : KS_RGBA1, hi = key ? KS_KEY1 : KS_RGBA2;
+        int        r = -1;
+        for (int k = lo; k <= hi && r < 0; ++k) {
+            if (owner[k] >= 0 && last_use[(size_t)owner[k]] < at) { /* previous tenant is dead */
+                reg[(size_t)owner[k]] = KS_NONE;
+                owner[k]              = -1;
             }
-            if (owner[r] < 0) {
-                owner[r]          = slot;
-                reg[(size_t)slot] = r;
-                KOp c;
-                std::memset(&c, 0, sizeof c);
-                c.kind = KOP_CLEAR;
-                c.dst  = r;
-                out->ops.push_back(c);
-                drawn[r] = pixel_box();
-                if (r == KS_RGBA1 || r == KS_RGBA2)
-                    out->full = true;
-                return r;
+            if (owner[k] < 0)
+                r = k;
+        }
+        if (r < 0 && key) {
+            /* Both key registers hold textures that are still needed: more than two key textures are alive at once
+               (a parent's pending layer key + a sublayer's layer key + its local key, image_mixer.cpp:104-114,153). The
+               one this draw does not use and that is needed again last goes to HBM; it comes back when a draw names it. */
+            const cghip_draw& d = draws[at];
+            int               best = -1, best_next = -1;
+            for (int k = lo; k <= hi; ++k) {
+                const int tenant = owner[k];
+                if (tenant == d.target || tenant == d.local_key || tenant == d.layer_key || tenant == d.source_surface)
+                    continue;
+                int next = ndraws;
+                for (int j = at; j < ndraws; ++j)
+                    if (emitted[(size_t)j] && (draws[j].target == tenant || draws[j].local_key == tenant ||
+                                               draws[j].layer_key == tenant || draws[j].source_surface == tenant)) {
+                        next = j;
+                        break;
+                    }
+                if (next > best_next)
+                    best = k, best_next = next;
+            }
+            if (best >= 0) {
+                marker(KOP_SAVE_KEY, best, owner[best]);
+                parked[(size_t)owner[best]] = 1;
+                reg[(size_t)owner[best]]    = KS_NONE;
+                owner[best]                 = -1;
+                r                           = best;
             }
         }
-        return -100;
+        if (r < 0)
+            return -100;
+        owner[r]          = slot;
+        reg[(size_t)slot] = r;
+        if (key && parked[(size_t)slot]) { /* back from HBM: no CLEAR, the launch loads it */
+            parked[(size_t)slot] = 0;
+            marker(KOP_LOAD_KEY, r, slot);
+            return r;
+        }
+        marker(KOP_CLEAR, r, KS_NONE);
+        drawn[r] = pixel_box();
+        if (r == KS_RGBA1 || r == KS_RGBA2)
+            out->full = true;
+        return r;
     };
     for (int i = 0; i < ndraws; ++i) {
         if (!emitted[(size_t)i])
@@ -1046,8 +1206,9 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
         op.layer_key   = bind(d.layer_key, i);
         op.dst         = bind(d.target, i);
         if (op.src_surface == -100 || op.local_key == -100 || op.layer_key == -100 || op.dst == -100)
-            return fail(CGHIP_ERR_UNSUPPORTED,
-                        "frame needs more than 2 live RGBA temporaries or 2 live key textures at once");
+            return fail(CGHIP_ERR_UNSUPPORTED, /* the reference's renderer never has more than a layer and a mix texture alive
+                                                    (image_mixer.cpp:128,187); key textures are unbounded and handled above */
+                        "frame needs more than 2 live RGBA temporaries at once");
         if (surfaces[d.target].channels == 1 && d.source_surface >= 0)
             return fail(CGHIP_ERR_INVALID, "surface-to-key draws do not exist in the reference renderer");
         /* A temporary is composited with a full-frame draw (image_mixer.cpp:207-225), but outside of what was drawn
@@ -1078,7 +1239,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
     }
     out->fast = true; /* with out->full: the variant of the fast kernel that also holds the two RGBA temporaries */
     for (const KOp& o : out->ops)
-        if (o.kind != KOP_CLEAR && o.fast_class == FC_NONE)
+        if (!is_marker(o) && o.fast_class == FC_NONE)
             out->fast = false;
     drop_hidden_ops(*fmt, out);
     fuse_layers(*fmt, out);
@@ -1114,6 +1275,8 @@ extern "C" int cghip_debug_kop_size(void) { return (int)sizeof(KOp); }
 
 /* test hooks: one launch of the general kernel per frame / at most n launches per frame (1 = never cut) */
 extern "C" void cghip_debug_force_general_kernel(int on) { cghip::g_force_general = on; }
+/* KOP_SAVE_KEY / KOP_LOAD_KEY markers stay in the op list cghip_debug_plan returns (never while rendering) */
+extern "C" void cghip_debug_keep_pseudo_ops(int on) { cghip::g_keep_pseudo_ops = on; }
 extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling = on; }
 /* sampled (scaled / rotated / perspective) draws stay with the 1-pixel-per-lane kernel, as before FC_SAMPLED existed */
 extern "C" void cghip_debug_no_sampled_fast(int on) { cghip::g_no_sampled_fast = on; }
@@ -1125,8 +1288,9 @@ extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1
 /* scales what the planner thinks a cut costs: 0 cuts at every change of class (tests: small frames never cut otherwise) */
 extern "C" void cghip_debug_cut_cost_scale(double scale) { cghip::g_cut_scale = scale >= 0.0 ? scale : 1.0; }
 
-/* Introspection: the launches of a planned frame, 10 ints each: first, count, fast, full, load_mask, store_mask,
- * gx0, gy0, gx1, gy1. Returns the number of segments. */
+/* Introspection: the launches of a planned frame, 14 ints each: first, count, fast, full, load_mask, store_mask,
+ * gx0, gy0, gx1, gy1, then the key buffers KEY0 / KEY1 are loaded from and stored to (-1: none). Returns the number of
+ * segments. */
 extern "C" int cghip_debug_plan_segments(const cghip_format* fmt, const cghip_surface* surfaces, int nsurfaces,
                                          const cghip_draw* draws, int ndraws, int* out, int capacity)
 {
@@ -1138,8 +1302,9 @@ extern "C" int cghip_debug_plan_segments(const cghip_format* fmt, const cghip_su
     for (const cghip::segment& sg : plan.segments) {
         if (k >= capacity)
             break;
-        const int v[10] = {sg.first, sg.count, sg.fast, sg.full, (int)sg.load_mask, (int)sg.store_mask, sg.gx0, sg.gy0, sg.gx1, sg.gy1};
-        std::memcpy(out + (size_t)k * 10, v, sizeof v);
+        const int v[14] = {sg.first, sg.count, sg.fast, sg.full, (int)sg.load_mask, (int)sg.store_mask, sg.gx0, sg.gy0, sg.gx1, sg.gy1,
+                           sg.key_ld[0], sg.key_ld[1], sg.key_st[0], sg.key_st[1]};
+        std::memcpy(out + (size_t)k * 14, v, sizeof v);
         ++k;
     }
     return (int)plan.segments.size();

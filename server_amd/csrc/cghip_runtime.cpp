@@ -576,8 +576,10 @@ static void ticket_free(cghip_ticket* t, hipStream_t also_drain = nullptr)
     dev->event_put(cghip_device::EV_ORDER, t->ev_ops);
     dev->dev_free(t->d_out, t->out_bytes);
     dev->dev_free(t->d_ops, t->ops_bytes);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
         dev->dev_free(t->spill[i], t->spill_bytes[i]);
+    for (void* kb : t->key_bufs)
+        dev->dev_free(kb, t->key_buf_bytes);
     dev->pinned_free(t->h_ops, t->ops_bytes);
     dev->pinned_free(t->h_out, t->out_bytes);
     for (cghip_plane* p : t->planes)
@@ -684,14 +686,23 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
     /* one launch per segment of the plan, in order on the mixer's stream; surfaces that are live across a cut travel
        through the frame buffer (RGBA0) and the ticket's spill buffers. An empty scene is one launch with zero ops
        that writes the all-zero frame (image_mixer.cpp:89-92). */
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
         if (plan.spill_mask & (1u << (KS_RGBA1 + i))) {
-            t->spill_bytes[i] = (size_t)format->width * format->height * (i < 2 ? 4 : 1) * (format->bits / 8);
+            t->spill_bytes[i] = (size_t)format->width * format->height * 4 * (format->bits / 8);
             T_TRY(dev->dev_alloc(t->spill_bytes[i], &t->spill[i]));
         }
+    t->key_buf_bytes = (size_t)format->width * format->height * (format->bits / 8);
+    for (int i = 0; i < plan.n_key_bufs; ++i) {
+        void* kb = nullptr;
+        T_TRY(dev->dev_alloc(t->key_buf_bytes, &kb));
+        t->key_bufs.push_back(kb);
+    }
+    auto key_buf = [&](int id) -> void* { return id >= 0 && id < (int)t->key_bufs.size() ? t->key_bufs[(size_t)id] : nullptr; };
     for (const segment& sg : plan.segments) {
         KSpill sp;
-        sp.rgba1 = t->spill[0], sp.rgba2 = t->spill[1], sp.key0 = t->spill[2], sp.key1 = t->spill[3];
+        sp.rgba1 = t->spill[0], sp.rgba2 = t->spill[1];
+        sp.key0 = key_buf(sg.key_ld[0]), sp.key1 = key_buf(sg.key_ld[1]);
+        sp.key0_st = key_buf(sg.key_st[0]), sp.key1_st = key_buf(sg.key_st[1]);
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
         sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
@@ -776,9 +787,9 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
     const size_t ops_only   = noalloc_ops_bytes();
     const size_t ops_region = ops_only + mask_region;
     size_t       off        = ops_region;
-    void*        spill[4]   = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 4; ++i)
-        if (plan.spill_mask & (1u << (KS_RGBA1 + i))) {
+    std::vector<void*> spill((size_t)(2 + plan.n_key_bufs), nullptr); /* RGBA1, RGBA2, then the key buffers (host memory) */
+    for (int i = 0; i < 2 + plan.n_key_bufs; ++i)
+        if (i >= 2 || (plan.spill_mask & (1u << (KS_RGBA1 + i)))) {
             const size_t need = round_up((size_t)format->width * format->height * (i < 2 ? 4 : 1) * (format->bits / 8), 256);
             if (off + need > cap) {
                 char msg[200];
@@ -788,9 +799,10 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
                          plan.segments.size(), cap - ops_region);
                 return fail(CGHIP_ERR_UNSUPPORTED, msg);
             }
-            spill[i] = (char*)base + off;
+            spill[(size_t)i] = (char*)base + off;
             off += need;
         }
+    auto key_buf = [&](int id) -> void* { return id >= 0 && id < plan.n_key_bufs ? spill[(size_t)(2 + id)] : nullptr; };
 
     std::lock_guard<std::mutex> lock(g_noalloc_mu[dev->gpu]); /* one frame at a time in a GPU's scratch array */
     hipStream_t                 st = mixer->stream;
@@ -828,7 +840,9 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
         if (e != hipSuccess)
             break;
         KSpill sp;
-        sp.rgba1 = spill[0], sp.rgba2 = spill[1], sp.key0 = spill[2], sp.key1 = spill[3];
+        sp.rgba1 = spill[0], sp.rgba2 = spill[1];
+        sp.key0 = key_buf(sg.key_ld[0]), sp.key1 = key_buf(sg.key_ld[1]);
+        sp.key0_st = key_buf(sg.key_st[0]), sp.key1_st = key_buf(sg.key_st[1]);
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
         sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;

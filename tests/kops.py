@@ -35,7 +35,7 @@ class KOp(C.Structure):
     ]
 
 
-KOP_CLEAR, KOP_DRAW_PLANES, KOP_DRAW_SURFACE = 0, 1, 2
+KOP_CLEAR, KOP_DRAW_PLANES, KOP_DRAW_SURFACE, KOP_SAVE_KEY, KOP_LOAD_KEY = 0, 1, 2, 3, 4
 (KF_LEVELS, KF_CSB, KF_CHROMA, KF_CHROMA_MASK, KF_INVERT, KF_IS_HD, KF_PROJECTIVE, KF_RECT, KF_UNIT_SCALE, KF_ADDITIVE,
  KF_SOLID, KF_EDGE, KF_RED_ONLY, KF_AXIS) = [1 << i for i in range(14)]
 FC_NONE, FC_PACKED, FC_PLANAR, FC_SURFACE, FC_SAMPLED, FC_UYVY, FC_BYTES = range(7)
@@ -62,7 +62,8 @@ def plan(fmt, surfaces, draws):
 last_plan_fast = False
 
 
-SEG_FIELDS = ("first", "count", "fast", "full", "load_mask", "store_mask", "gx0", "gy0", "gx1", "gy1")
+SEG_FIELDS = ("first", "count", "fast", "full", "load_mask", "store_mask", "gx0", "gy0", "gx1", "gy1",
+              "key_ld0", "key_ld1", "key_st0", "key_st1")
 
 
 def plan_segments(fmt, surfaces, draws):
@@ -71,12 +72,12 @@ def plan_segments(fmt, surfaces, draws):
     L = A.lib()
     sa = (A.Surface * len(surfaces))(*[A.Surface(c, 0) for c in surfaces])
     da = (A.Draw * max(1, len(draws)))(*draws)
-    out = (C.c_int * (10 * 64))()
+    out = (C.c_int * (14 * 64))()
     n = L.cghip_debug_plan_segments(C.byref(fmt), sa, len(surfaces), da, len(draws), out, 64)
     if n < 0:
         raise A.CGHIPError(n, L.cghip_last_error().decode())
     assert n <= 64
-    return [dict(zip(SEG_FIELDS, out[i * 10:(i + 1) * 10])) for i in range(n)]
+    return [dict(zip(SEG_FIELDS, out[i * 14:(i + 1) * 14])) for i in range(n)]
 
 
 def set_cut_policy(cut_cost_scale=1.0, max_segments=8, sampled_fast=True):

@@ -215,6 +215,26 @@ def small_scenes():
                    [bg, [("push", dict(layer_depth=1, fill_scale=[0.8, 0.8], fill_translation=[0.1, 0.1], angle=0.1, opacity=0.9)),
                          ("push", dict(fill_scale=[0.5, 0.9], fill_translation=[0.2, 0.0], brightness=1.1, crop_ul=[0.1, 0.0])),
                          ("visit", bgra(W, H, "smooth", 52)), ("pop",), ("pop",)]]))
+    # More than two key textures alive at once (image_mixer.cpp:104-114,153): the key a top-level layer left for the next
+    # one (k1) stays pending while that layer's sublayers run their own chain - sublayer S1 leaves kS1 for S2, S2 draws a
+    # local key kS2 and a fill that uses kS2 and kS1 - and is consumed by the layer's own item afterwards. The kernels
+    # hold two key surfaces: the planner parks the third in HBM across a cut (KOP_SAVE_KEY / KOP_LOAD_KEY).
+    def nested(depth, seed):
+        inner = [("push", dict(layer_depth=1)),
+                 ("push", dict(is_key=1)), ("visit", ycbcr(W, H, "422", "smooth", seed + 1)), ("pop",),
+                 ("push", dict(opacity=0.8)), ("visit", bgra(W, H, "premul", seed + 2)), ("pop",),
+                 ("pop",)]
+        for d in range(depth):
+            inner = [("push", dict(layer_depth=1)),
+                     ("push", dict(layer_depth=1, is_key=1)), ("visit", bgra(W, H, "smooth", seed + 10 + d)), ("pop",)] + inner + \
+                    [("push", dict(opacity=0.9 - 0.1 * d, fill_scale=[0.9, 0.9])), ("visit", ycbcr(W, H, "420", "video", seed + 20 + d)), ("pop",),
+                     ("pop",)]
+        return inner
+    S.append(scene("nested_sublayer_keys", W, H,
+                   [bg, layer(bgra(W, H, "smooth", 70), is_key=1), nested(1, 71)]))
+    S.append(scene("nested_sublayer_keys_deep", W, H,
+                   [bg, layer(ycbcr(W, H, "444", "smooth", 75), is_key=1), nested(3, 76),
+                    layer(bgra(W, H, "premul", 79), opacity=0.5)]))
     S.append(scene("empty_scene", W, H, []))
     return S
 

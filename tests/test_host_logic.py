@@ -311,7 +311,9 @@ def check_segments(ops, segs, W, H):
     assert segs and segs[0]["first"] == 0 and sum(s["count"] for s in segs) == len(ops)
     ZERO = 0
     true = [ZERO] * 5   # value a single launch would hold
-    mem = [None] * 5    # value in HBM (None: never written)
+    mem = [None] * 5    # value in HBM (None: never written); the key registers' values live in numbered key buffers
+    keybuf = {}         # key buffer id -> value
+    parked = {}         # surface slot -> value of a key texture that left its register (KOP_SAVE_KEY)
     version = 0
     for si, sg in enumerate(segs):
         assert sg["first"] == (segs[si - 1]["first"] + segs[si - 1]["count"] if si else 0)
@@ -325,11 +327,23 @@ def check_segments(ops, segs, W, H):
         regs = [ZERO] * 5
         for s in range(5):
             if sg["load_mask"] & (1 << s):
-                assert mem[s] is not None, (si, s, "loads a surface nobody stored")
-                regs[s] = mem[s]
+                if s >= 3:
+                    b = sg["key_ld%d" % (s - 3)]
+                    assert b in keybuf, (si, s, b, "loads a key buffer nobody stored")
+                    regs[s] = keybuf[b]
+                else:
+                    assert mem[s] is not None, (si, s, "loads a surface nobody stored")
+                    regs[s] = mem[s]
         for o in ops[sg["first"]:sg["first"] + sg["count"]]:
             if o.kind == K.KOP_CLEAR:
                 regs[o.dst] = true[o.dst] = ZERO
+                continue
+            if o.kind == K.KOP_SAVE_KEY:  # (only with cghip_debug_keep_pseudo_ops) the key texture leaves its register
+                parked[o.src_surface] = true[o.dst]
+                continue
+            if o.kind == K.KOP_LOAD_KEY:  # ... and comes back: the launch must have loaded exactly that value
+                true[o.dst] = parked.pop(o.src_surface)
+                assert regs[o.dst] == true[o.dst], (si, o.dst, "a parked key texture came back with another value")
                 continue
             if not sg["full"]:
                 assert o.dst not in (1, 2) and o.kind != K.KOP_DRAW_SURFACE
@@ -350,8 +364,12 @@ def check_segments(ops, segs, W, H):
         for s in range(5):
             if sg["store_mask"] & (1 << s):
                 # a boxed launch rewrites only its box of RGBA0; outside it the registers were loaded from mem
-                mem[s] = regs[s]
-    assert mem[0] == true[0]
+                if s >= 3:
+                    assert sg["key_st%d" % (s - 3)] >= 0
+                    keybuf[sg["key_st%d" % (s - 3)]] = regs[s]
+                else:
+                    mem[s] = regs[s]
+    assert mem[0] == true[0] and not parked
 
 
 def mixed_scene(W, H, bits=8, n_before=6, n_after=6):
@@ -459,6 +477,35 @@ def test_nested_blend_sublayer_with_a_mix_pair_fits_two_temporaries():
     _d, surfaces, ops, full = product_plan(nested)
     assert len(surfaces) == 4 and full and {o.dst for o in ops} == {0, 1, 2}
     assert len(oracle_log(nested)) == 7
+
+
+def test_more_than_two_live_key_textures_are_parked_in_hbm_across_cuts():
+    """image_mixer.cpp:104-114,153: every nesting level of sublayers has a pending layer key of its own, so a frame can
+    have any number of key textures alive at once; the kernels hold two. The planner (round 3; rounds 1 - 2 refused such
+    frames with CGHIP_ERR_UNSUPPORTED) parks the texture that is needed again last in HBM: KOP_SAVE_KEY in front of a
+    cut, KOP_LOAD_KEY behind a later one. Replayed here with the markers kept in the op list: every draw sees the value
+    a renderer with unlimited textures would, and a parked texture comes back unchanged. Pixel parity: the golden
+    scenes nested_sublayer_keys / nested_sublayer_keys_deep (CPU: oracle vs llvmpipe; GPU: HIP vs both)."""
+    by_name = {s["name"]: s for s in S.small_scenes()}
+    L = A.lib()
+    for name, n_saves, n_bufs in (("nested_sublayer_keys", 1, 2), ("nested_sublayer_keys_deep", 3, 4)):
+        sc = by_name[name]
+        draws, surfaces, ops_plain, _full = product_plan(sc)
+        assert len([c for c in surfaces if c == 1]) == n_saves + 2  # key textures the reference would create
+        L.cghip_debug_keep_pseudo_ops(1)
+        try:
+            ops, segs = plan_with_segments(sc)
+        finally:
+            L.cghip_debug_keep_pseudo_ops(0)
+        assert sum(o.kind == K.KOP_SAVE_KEY for o in ops) == n_saves == sum(o.kind == K.KOP_LOAD_KEY for o in ops)
+        check_segments(ops, segs, sc["width"], sc["height"])
+        used = {s[k] for s in segs for k in ("key_ld0", "key_ld1", "key_st0", "key_st1")} - {-1}
+        assert used == set(range(n_bufs)), used
+        # what the kernels get: no markers, same launches
+        ops2, segs2 = plan_with_segments(sc)
+        assert all(o.kind <= K.KOP_DRAW_SURFACE for o in ops2) and len(ops2) == len(ops) - 2 * n_saves == len(ops_plain)
+        assert len(segs2) == len(segs) and sum(s["count"] for s in segs2) == len(ops2)
+        assert len(oracle_log(sc)) == len(draws)
 
 
 def test_empty_scene_is_one_launch_that_stores_the_frame():
