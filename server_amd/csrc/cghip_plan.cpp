@@ -592,18 +592,30 @@ static void drop_hidden_ops(const cghip_format& fmt, frame_plan* out)
     std::vector<KOp>&    ops = out->ops;
     std::vector<uint8_t> keep(ops.size(), 0);
     uint32_t             live = 1u << KS_RGBA0; /* surfaces whose value at this point still matters */
+    std::vector<int>     wanted;                /* parked key textures (surface slots) a kept KOP_LOAD_KEY brings back */
     bool                 any_dropped = false;
     for (size_t i = ops.size(); i-- > 0;) {
         const KOp&     o   = ops[i];
         const uint32_t dst = o.dst >= 0 && o.dst < KS_COUNT ? 1u << o.dst : 0u;
-        if (o.kind == KOP_SAVE_KEY) { /* never dropped (its LOAD may be kept): the register's value matters here */
-            keep[i] = 1;
-            live |= dst;
-            continue;
-        }
-        if (o.kind == KOP_LOAD_KEY) { /* rewrites its register: what was there before is dead */
+        if (o.kind == KOP_LOAD_KEY) { /* rewrites its register: what was there before is dead; needs its SAVE */
+            if (!(live & dst)) {
+                any_dropped = true;
+                continue;
+            }
             keep[i] = 1;
             live &= ~dst;
+            wanted.push_back(o.src_surface);
+            continue;
+        }
+        if (o.kind == KOP_SAVE_KEY) { /* kept iff the texture it parks comes back: then the register's value matters here */
+            auto w = std::find(wanted.begin(), wanted.end(), o.src_surface);
+            if (w == wanted.end()) {
+                any_dropped = true;
+                continue;
+            }
+            wanted.erase(w);
+            keep[i] = 1;
+            live |= dst;
             continue;
         }
         if (!(live & dst)) {

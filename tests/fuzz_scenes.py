@@ -235,3 +235,52 @@ def fuzz_box_scene(seed, bits=8, full=False):
             t["blend_mode"] = rng.choice(S.BLEND_NAMES)
         ops.append(S.layer(src, **t))
     return S.scene("fuzzbox_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 0, 1, 2]))
+
+
+def fuzz_nested_scene(seed, bits=8):
+    """Random stacks with NESTED sublayers that carry keys of their own: every nesting level keeps a pending layer key
+    (image_mixer.cpp:104-114,153), so three to five key textures are alive at once where the kernels hold two - the
+    planner parks the rest in HBM across cuts (KOP_SAVE_KEY / KOP_LOAD_KEY). Sources of both kernel classes."""
+    rng = random.Random(5000017 * seed + bits)
+    W, H = rng.choice([(96, 64), (128, 36), (64, 48), (130, 50)])
+    s = 20000 + 173 * seed
+    n = [0]
+
+    def src(unit):
+        n[0] += 1
+        if unit:
+            f = rng.choice(["bgra", "ycbcr422", "ycbcr420", "ycbcr444"])
+            if f == "bgra":
+                return S.frame("bgra", [(W, H, 4, rng.choice(["premul", "smooth"]), s + n[0])], bits)
+            return S.ycbcr(W, H, f[-3:], rng.choice(["smooth", "video"]), s + n[0], bits=bits)
+        return _source(rng, W, H, bits, s + n[0])
+
+    def item(**t):
+        unit = rng.random() < 0.6
+        if not unit and rng.random() < 0.7:
+            t.update(_transform(rng, False))
+        elif rng.random() < 0.5:
+            t["opacity"] = rng.choice([1.0, 0.5, 0.73, round(rng.random(), 3)])
+        return [("push", t), ("visit", src(unit)), ("pop",)]
+
+    def layer_with_sublayers(depth):
+        ops = [("push", dict(layer_depth=1, **({"blend_mode": rng.choice(S.BLEND_NAMES)} if rng.random() < 0.2 else {})))]
+        if depth > 0:
+            for _ in range(rng.randint(1, 2)):
+                if rng.random() < 0.7:  # a key sublayer in front of the next one
+                    ops += [("push", dict(layer_depth=1, is_key=1)), ("visit", src(True)), ("pop",)]
+                ops += layer_with_sublayers(depth - 1)
+        if rng.random() < 0.6:  # local key + fill
+            ops += item(is_key=1)
+        ops += item()
+        if rng.random() < 0.3:
+            ops += item()
+        ops.append(("pop",))
+        return ops
+
+    ops = [S.layer(S.bgra(W, H, "premul", s))]
+    for _ in range(rng.randint(1, 3)):
+        if rng.random() < 0.7:
+            ops.append(S.layer(src(True), is_key=1))  # leaves a pending key for the next top-level layer
+        ops.append(layer_with_sublayers(rng.randint(1, 3)))
+    return S.scene("fuzznested_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 0, 1, 2]))

@@ -466,3 +466,34 @@ def test_draws_hidden_by_an_opaque_full_frame_layer_are_dropped_without_a_trace(
             assert st["max"] <= 1 and st["gt0"] <= 1e-4, (seed, st)
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
+def test_nested_sublayers_with_keys_match_the_oracle(bits):
+    """Frames with more key textures alive than the kernels have key registers (fuzz_nested_scene: nested sublayers with
+    keys of their own): the planner parks key textures in HBM across cuts. 8-bit frames bit-exact against the oracle
+    (levels gamma: 1 LSB), 16-bit frames to tests/parity16.py's bar; most scenes must actually need the parking."""
+    import kops as K
+    import server_amd as A
+    from fuzz_scenes import fuzz_nested_scene
+    m = A.Mixer(channel_id=12, gpu=0)
+    multi = 0
+    try:
+        for seed in range(150):
+            sc = fuzz_nested_scene(seed, bits)
+            cache = {}
+            before = m.device_info()["kernel_launches"]
+            got = S.run_product(sc, mixer=m, planes_cache=cache)
+            multi += m.device_info()["kernel_launches"] - before > 1
+            ref = S.run_oracle(sc, "cpu", cache)
+            if bits == 8:
+                st = S.diff_stats(got, ref)
+                pow_used = any(o[0] == "push" and o[1].get("levels_gamma", 1.0) != 1.0 for o in sc["ops"])
+                assert (st["max"] <= 1 and st["gt0"] <= 1e-4) if pow_used else st["max"] == 0, (seed, st)
+            else:
+                st = P16.check(sc, got, ref, cache)
+                assert st["max_outside_amplifying"] <= P16.LIMIT, (seed, st)
+    finally:
+        m.close()
+    assert multi > 75, multi

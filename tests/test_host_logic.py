@@ -508,6 +508,23 @@ def test_more_than_two_live_key_textures_are_parked_in_hbm_across_cuts():
         assert len(oracle_log(sc)) == len(draws)
 
 
+def test_random_nested_key_scenes_replay_correctly():
+    """The same replay over 200 random nested scenes (tests/fuzz_scenes.py: fuzz_nested_scene), markers kept."""
+    from fuzz_scenes import fuzz_nested_scene
+    L = A.lib()
+    parked = 0
+    L.cghip_debug_keep_pseudo_ops(1)
+    try:
+        for seed in range(200):
+            sc = fuzz_nested_scene(seed, 8)
+            ops, segs = plan_with_segments(sc)
+            check_segments(ops, segs, sc["width"], sc["height"])
+            parked += any(o.kind == K.KOP_SAVE_KEY for o in ops)
+    finally:
+        L.cghip_debug_keep_pseudo_ops(0)
+    assert parked > 100, parked
+
+
 def test_empty_scene_is_one_launch_that_stores_the_frame():
     fmt = A.Format(64, 64, 64, 64, 8, 0)
     segs = K.plan_segments(fmt, [4], [])
