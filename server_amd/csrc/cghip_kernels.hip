@@ -42,6 +42,12 @@
 
 /* relaxed numerics: the object for 16-bit frames (see divf below) */
 constexpr bool RXF = CGHIP_FRAME_BITS == 16;
+DEV int opaque_s(int v); /* below: a scalar the compiler may not look through */
+/* A per-pixel block of a 4-pixel body behind a branch of its own (always taken; the compiler cannot know). Measured,
+ * not understood: the chroma key of four pixels as ONE straight-line block of 258 instructions ran slower than the same
+ * code as four blocks with a scalar branch in front of each (16 chroma-key layers at 2160p, 16-bit: 0.295 -> 0.279 ms;
+ * 8-bit 0.440 -> 0.395), although tests/ubench finds no cost in dependent chains or register banks at 7 waves. */
+#define PX_BRANCH if (opaque_s(1))
 
 /* compile-time loop: the per-pixel register arrays must never be indexed dynamically (that would put them
  * in scratch memory) */
@@ -350,8 +356,18 @@ DEV f3 hsv2rgb(f3 c)
               c.z * mixf(1.0f, clamp01(p.z - 1.0f), c.y)};
 }
 
-/* shader.frag:323-383,436-439; colour in internal order */
-template <bool RX = false, class P>
+/* hue distance wrapped to [-0.5, 0.5] (shader.frag:349-353: +1 below -0.5, -1 above 0.5): the nearest integer, held to
+ * -1..1, subtracted - three instructions for two compares, two adds and two selects, and the same number for every
+ * input (the subtraction IS that add; rint(+-0.5) is 0 like the strict compares) */
+DEV float wrap_hue(float diff)
+{
+    return diff - __builtin_amdgcn_fmed3f(__builtin_rintf(diff), -1.0f, 1.0f);
+}
+
+/* shader.frag:323-383,436-439; colour in internal order. MASK: 1 / 0 = the caller has tested KF_CHROMA_MASK (once for
+ * the four pixels of a lane: inside the per-pixel function the wave-uniform test became a branch and two vector
+ * instructions per pixel), -1 = test it here. */
+template <bool RX = false, int MASK = -1, class P>
 DEV f4 chroma_key(f4 c, const P& op)
 {
     const f3    hsv      = rgb2hsv<RX>(f3{c.z, c.y, c.x}); /* c.bgra -> real r,g,b */
@@ -362,20 +378,68 @@ DEV f4 chroma_key(f4 c, const P& op)
     const float hueScore = hueDiff - op.ch_hue_width;
     const float distance = -hueScore * sbScore;
     const float dd       = distance * -2.0f + 1.0f;
-    f3          sp       = hsv;
-    float       diff     = hsv.x - op.ch_target_hue;
-    diff                 = diff < -0.5f ? diff + 1.0f : (diff > 0.5f ? diff - 1.0f : diff);
-    const float dist     = divc<RX>(__builtin_fabsf(diff), op.ch_spill, op.ch_inv_spill);
+    const float t        = clamp01(divc<RX>(dd - 1.0f, op.ch_soft_range, op.ch_inv_soft)); /* smoothstep(1, softness, d) */
+    const float alpha    = 1.0f - t * t * (3.0f - 2.0f * t);
+    if (MASK > 0 || (MASK < 0 && (op.flags & KF_CHROMA_MASK)))
+        return f4{alpha, alpha, alpha, 1.0f};
+    f3          sp   = hsv;
+    const float diff = wrap_hue(hsv.x - op.ch_target_hue);
+    const float dist = divc<RX>(__builtin_fabsf(diff), op.ch_spill, op.ch_inv_spill);
     if (dist < 1.0f) {
         sp.x = diff < 0.0f ? op.ch_target_hue - op.ch_spill : op.ch_target_hue + op.ch_spill;
         sp.y *= __builtin_fminf(1.0f, dist + op.ch_spill_saturation);
     }
-    const f3    rgb   = hsv2rgb(sp);
-    const float t     = clamp01(divc<RX>(dd - 1.0f, op.ch_soft_range, op.ch_inv_soft)); /* smoothstep(1, softness, d) */
-    const float alpha = 1.0f - t * t * (3.0f - 2.0f * t);
-    if (op.flags & KF_CHROMA_MASK)
-        return f4{alpha, alpha, alpha, 1.0f};
+    const f3 rgb = hsv2rgb(sp);
     return f4{rgb.z * alpha, rgb.y * alpha, rgb.x * alpha, alpha}; /* back to internal order */
+}
+
+/* The same for four pixels of the relaxed (16-bit) build, where a few 1e-7 do not matter (divf): value and chroma as
+ * max3 / min3 (the shader's select cascade sorts the channels; only the hue still needs it), ONE wrapped hue distance
+ * w for the hue score (2 |w|, the shader's 0.5 - ||h - t| - 0.5| doubled) and the spill band (|w| / spill), the
+ * smoothstep argument as one multiply by -2 / softness, v_fract for fract(), value * alpha before the three channels.
+ * 59 vector instructions per pixel, 79 as the compiler made them from chroma_key(). */
+struct ChromaRx {
+    float target, width, min_sat, min_bri, hue_lo, hue_hi, inv_spill, spill_sat, m2_inv_soft;
+    template <class P>
+    explicit DEV ChromaRx(const P& o)
+        : target(o.ch_target_hue), width(o.ch_hue_width), min_sat(o.ch_min_saturation), min_bri(o.ch_min_brightness),
+          hue_lo(o.ch_target_hue - o.ch_spill), hue_hi(o.ch_target_hue + o.ch_spill), inv_spill(o.ch_inv_spill),
+          spill_sat(o.ch_spill_saturation), m2_inv_soft(-2.0f * o.ch_inv_soft)
+    {
+    }
+};
+template <bool MASK>
+DEV f4 chroma_key_relaxed(f4 c, const ChromaRx& k)
+{
+    const float r = c.z, g = c.y, b = c.x;
+    const bool  gb = !(g < b);
+    const float px = gb ? g : b, py = gb ? b : g, pz = gb ? 0.0f : -1.0f, pw = gb ? -1.0f / 3.0f : 2.0f / 3.0f;
+    const bool  rp = !(r < px);
+    const float v = rp ? r : px, qz = rp ? pz : pw, qw = rp ? px : r;
+    const float d = v - __builtin_fminf(__builtin_fminf(r, g), b);
+    const float e = 1.0e-10f;
+    const float h = __builtin_fabsf(__builtin_fmaf(qw - py, __builtin_amdgcn_rcpf(__builtin_fmaf(6.0f, d, e)), qz));
+    const float s = d * __builtin_amdgcn_rcpf(v + e);
+    const float w = wrap_hue(h - k.target), aw = __builtin_fabsf(w);
+    const float hueScore = __builtin_fmaf(aw, 2.0f, -k.width);
+    const float sbScore  = __builtin_fmaxf(__builtin_fminf(0.0f, k.min_bri - v), __builtin_fminf(0.0f, k.min_sat - s));
+    const float t        = clamp01((hueScore * sbScore) * -k.m2_inv_soft); /* distance = -hueScore * sbScore */
+    const float alpha    = __builtin_fmaf(-(t * t), __builtin_fmaf(-2.0f, t, 3.0f), 1.0f);
+    if (MASK)
+        return f4{alpha, alpha, alpha, 1.0f};
+    const float dist = aw * k.inv_spill;
+    const bool  in   = dist < 1.0f;
+    const float sh   = in ? (w < 0.0f ? k.hue_lo : k.hue_hi) : h;
+    const float ss   = in ? s * __builtin_fminf(1.0f, dist + k.spill_sat) : s;
+    /* v * mix(1, c, s) * alpha with c = clamp(|p| - 1), p = fract(h + off) * 6 - 3, as va - (va * s) * clamp(2 - |p|):
+       1 - clamp(|p| - 1) is clamp(2 - |p|) for |p| in [0, 3] */
+    const float va = v * alpha, vas = va * ss;
+    auto chan = [&](float hue) {
+        const float p = __builtin_fmaf(__builtin_amdgcn_fractf(hue), 6.0f, -3.0f);
+        return __builtin_fmaf(-vas, clamp01(2.0f - __builtin_fabsf(p)), va);
+    };
+    const float R = chan(sh), G = chan(sh + 2.0f / 3.0f), B = chan(sh + 1.0f / 3.0f);
+    return f4{B, G, R, alpha};
 }
 
 /* shader.frag:76-86 */
@@ -396,6 +460,47 @@ DEV float levels1(float c, const P& op)
     if constexpr (RX)
         return __builtin_fmaf(r, op.lv_max_output - op.lv_min_output, op.lv_min_output);
     return mixf(op.lv_min_output, op.lv_max_output, r);
+}
+
+/* levels1() on the three colours of four pixels, with its two wave-uniform questions (gamma != 1, output range other
+ * than [0,1]) asked ONCE, as branches: inside the per-sample function the compiler turned both into per-sample selects
+ * and evaluated the unused output mix anyway - 7 instructions per sample where the usual levels (gamma only) need 4
+ * (36 cycles -> 22 by tests/ubench's rates). Same arithmetic per sample, so the 8-bit build stays bit-identical. */
+template <bool RX = false, class P>
+DEV void levels12(f4 col[4], const P& op)
+{
+    float* c[12] = {&col[0].x, &col[0].y, &col[0].z, &col[1].x, &col[1].y, &col[1].z,
+                    &col[2].x, &col[2].y, &col[2].z, &col[3].x, &col[3].y, &col[3].z};
+    float  off = 0.0f;
+    if constexpr (RX)
+        off = -op.lv_min_input * op.lv_inv_range;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        if constexpr (RX)
+            *c[k] = clamp01(__builtin_fmaf(*c[k], op.lv_inv_range, off));
+        else
+            *c[k] = __builtin_fminf(div_const(__builtin_fmaxf(*c[k] - op.lv_min_input, 0.0f), op.lv_range, op.lv_inv_range), 1.0f);
+    }
+    if (op.lv_inv_gamma != 1.0f) { /* wave-uniform; the empty asm keeps it a branch */
+        asm volatile("");
+        float g = op.lv_inv_gamma;
+        asm volatile("" : "+v"(g)); /* a VGPR: twelve uses, and an SGPR operand halves the issue rate */
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            *c[k] = __builtin_amdgcn_exp2f(g * __builtin_amdgcn_logf(*c[k]));
+    }
+    if (!(op.lv_min_output == 0.0f && op.lv_max_output == 1.0f)) { /* wave-uniform and rare */
+        asm volatile("");
+        float lo = op.lv_min_output, hi = op.lv_max_output;
+        asm volatile("" : "+v"(lo), "+v"(hi));
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            if constexpr (RX)
+                *c[k] = __builtin_fmaf(*c[k], hi - lo, lo);
+            else
+                *c[k] = mixf(lo, hi, *c[k]);
+        }
+    }
 }
 
 /* shader.frag:48-70 */
@@ -671,8 +776,14 @@ DEV f4 source_color_unit(const KOp& op, int px, int py)
 /* shader.frag:526-531: chroma key, levels, CSB on the source colour */
 DEV f4 shade_adjust(const KOp& op, f4 color)
 {
-    if (op.flags & KF_CHROMA)
-        color = chroma_key<RXF>(color, op);
+    if (op.flags & KF_CHROMA) {
+        if constexpr (RXF) { /* the arithmetic of the 4-pixel kernels: the same layer gives the same pixels in either */
+            const ChromaRx k(op);
+            color = (op.flags & KF_CHROMA_MASK) ? chroma_key_relaxed<true>(color, k) : chroma_key_relaxed<false>(color, k);
+        } else {
+            color = chroma_key<false>(color, op);
+        }
+    }
     if (op.flags & KF_LEVELS) {
         color.x = levels1<RXF>(color.x, op);
         color.y = levels1<RXF>(color.y, op);
@@ -1851,6 +1962,7 @@ DEV void store_rgba4(const Fore& o, f4 S[4])
     }
     static_for<0, 4>([&](auto I) {
         constexpr int i = decltype(I)::value;
+        if (BITS == 16 || opaque_s(1)) /* PX_BRANCH in the 8-bit build: config 3 at 8 bits 0.252 -> 0.248 ms; nothing at 16 */
         S[i] = f4{quantize<BITS>(o.f[i].x + o.ia[i] * S[i].x), quantize<BITS>(o.f[i].y + o.ia[i] * S[i].y),
                   quantize<BITS>(o.f[i].z + o.ia[i] * S[i].z), quantize<BITS>(o.f[i].w + o.ia[i] * S[i].w)};
     });
@@ -2330,14 +2442,24 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
         /* shader.frag:526-531, each adjustment one wave-uniform branch around all four pixels */
         if (h.flags & KF_CHROMA) {
             const ChromaV cp(op);
-            static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key<RXF>(col[decltype(I)::value], cp); });
+            /* two ifs with the second test opaque, not if / else: see the stores below */
+            const bool mask = cp.flags & KF_CHROMA_MASK, plain = !(opaque_s((int)cp.flags) & KF_CHROMA_MASK);
+            if constexpr (RXF) {
+                const ChromaRx k(cp);
+                if (mask)
+                    static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key_relaxed<true>(col[decltype(I)::value], k); });
+                if (plain)
+                    static_for<0, P>([&](auto I) { PX_BRANCH col[decltype(I)::value] = chroma_key_relaxed<false>(col[decltype(I)::value], k); });
+            } else {
+                if (mask)
+                    static_for<0, P>([&](auto I) { col[decltype(I)::value] = chroma_key<false, 1>(col[decltype(I)::value], cp); });
+                if (plain)
+                    static_for<0, P>([&](auto I) { PX_BRANCH col[decltype(I)::value] = chroma_key<false, 0>(col[decltype(I)::value], cp); });
+            }
         }
         if (h.flags & KF_LEVELS) {
             const LevelsV lp(op);
-            static_for<0, P>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                col[i].x = levels1<RXF>(col[i].x, lp), col[i].y = levels1<RXF>(col[i].y, lp), col[i].z = levels1<RXF>(col[i].z, lp);
-            });
+            levels12<RXF>(col, lp);
         }
         if (h.flags & KF_CSB) {
             const CsbV bp(op);
