@@ -517,14 +517,29 @@ int cghip_mixer_create(cghip_device* dev, int channel_id, cghip_mixer** out)
     CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
     cghip_mixer* m = new cghip_mixer();
     m->dev = dev, m->channel_id = channel_id;
-    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    /* Stream priorities (opt-in: CGHIP_STREAM_PRIORITIES=1). The frame's D2H copy is a shader copy on this platform
+       (`__amd_rocclr_copyBuffer` in the kernel trace, not an SDMA transfer) bound by PCIe: 0.59 ms for a 33 MB frame. It
+       needs few waves but it needs them while the next frame composites, and the compositor fills every wave slot of the
+       chip (7 x 72 VGPRs per SIMD): with two plain streams the copy waits for slots, and on some boxes a channel with
+       readback runs at nearly the serial sum of kernel and copy (config 3 8-bit 0.93 ms per frame, 16-bit 1.44; other
+       boxes 0.69 / 1.25). With the compositor's stream at the lowest priority and the readback stream at the highest the
+       same box gave 0.69 and 1.24 ms = 86 % and 94 % of the copy alone (tests/gpu_readback_prio.sh). NOT the default:
+       with priorities on, one render of the random-scene suite (tests/test_fuzz.py) never completed - a frame's event
+       was never signalled - and the cause inside the runtime's queue scheduling was not found in round 3. */
+    int         least = 0, greatest = 0;
+    const char* sp    = std::getenv("CGHIP_STREAM_PRIORITIES");
+    const bool  prio  = sp != nullptr && std::atoi(sp) != 0 &&
+                       hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least;
+    hipError_t  e     = prio ? hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, least)
+                             : hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) {
         e = hipStreamCreateWithFlags(&m->ops_stream, hipStreamNonBlocking);
         if (e != hipSuccess)
             (void)hipStreamDestroy(m->stream);
     }
     if (e == hipSuccess) {
-        e = hipStreamCreateWithFlags(&m->readback_stream, hipStreamNonBlocking);
+        e = prio ? hipStreamCreateWithPriority(&m->readback_stream, hipStreamNonBlocking, greatest)
+                 : hipStreamCreateWithFlags(&m->readback_stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             (void)hipStreamDestroy(m->ops_stream);
             (void)hipStreamDestroy(m->stream);

@@ -2,6 +2,11 @@
 # parity + the default bench line after a runtime / kernel change (run through gpurun)
 set -o pipefail
 mkdir -p gpurun_out
+# the first `import torch` on a fresh box pages in for a minute or two, and the first test starts two more processes
+# that do the same: say so every 30 s (every test has its own --timeout, a real hang still ends the run)
+( while sleep 30; do echo "[quick check] running"; done ) &
+HEART=$!
+trap 'kill $HEART 2>/dev/null' EXIT
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1 || { echo "tests failed"; tail -20 gpurun_out/gpu_tests.log; exit 1; }
 tail -2 gpurun_out/gpu_tests.log
 timeout -k 10 400 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err || { echo "bench failed"; tail -5 gpurun_out/bench_default.err; exit 1; }
