@@ -187,6 +187,10 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
 
 /* ---- tickets: replaces future<array<const uint8_t>>::get (common/future.h:9-27) --------------- */
 int cghip_ticket_wait(cghip_ticket* ticket, const uint8_t** data, size_t* size); /* needs CGHIP_RENDER_READBACK */
+/* The frame as the GPU sees it. Normally the frame buffer in HBM; for a frame rendered with CGHIP_RENDER_READBACK as one
+ * launch it is the pinned host buffer itself (direct readback: the launch stores across PCIe) -
+ * device-accessible, but reads from it cross PCIe. Render without CGHIP_RENDER_READBACK, or with
+ * CGHIP_READBACK_DIRECT=0 in the environment, for a frame that a GPU consumer reads. */
 int cghip_ticket_device_ptr(cghip_ticket* ticket, const void** device_ptr, size_t* size);
 /* hipEvent time of the frame's launches in ms; -1 for a frame rendered with CGHIP_RENDER_UNTIMED */
 int cghip_ticket_kernel_ms(cghip_ticket* ticket, float* ms, int* launches);

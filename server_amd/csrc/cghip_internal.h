@@ -97,6 +97,7 @@ struct cghip_mixer {
     cghip_device* dev        = nullptr;
     int           channel_id = 0;
     hipStream_t   stream     = nullptr; /* compositor of this channel */
+    unsigned      direct_frames = 0; /* direct readback: which of the two streams the next such frame takes */
     hipStream_t   ops_stream = nullptr; /* uploads a frame's op list while the previous frame is still compositing */
     hipStream_t   readback_stream = nullptr; /* D2H of finished frames (device.cpp:264-302): frame n crosses PCIe while
                                                 frame n + 1 composites; on the compositor's stream its 33 - 66 MB copy

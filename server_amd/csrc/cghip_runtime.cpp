@@ -619,8 +619,25 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
 
     cghip_device* dev = mixer->dev;
     CGHIP_TRY_HIP(hipSetDevice(dev->gpu));
+    /* Direct readback: a frame that is ONE launch over the whole frame and is read back anyway writes its pixels straight
+       into the pinned host buffer. The runtime's D2H copy into pinned memory is a shader copy on this platform
+       (`__amd_rocclr_copyBuffer` in the kernel trace, no SDMA transfer): a second pass over the frame whose waves compete
+       with the next frame's launch for wave slots, and how that went depended on the box (one channel, config 3 at 8
+       bits: 0.69 - 0.93 ms per frame; the copy alone 0.59). Here the launch's own stores cross PCIe: 0.68 ms (87 % of the
+       copy's rate) and 1.28 ms at 16 bits (92 %) on every box, no frame buffer in HBM, no second stream to order
+       (tests/gpu_readback_direct.sh). Several channels on a GPU reach the link's rate either way (52 GB/s). The price: the
+       launch's hipEvent time then includes the drain over PCIe, and cghip_ticket_device_ptr hands out the pinned
+       buffer. Frames cut into several launches (RGBA0 travels in the frame buffer between them) and field-row
+       readbacks keep the copy. CGHIP_READBACK_DIRECT=0 switches it off. */
+    static const bool direct_env = [] { const char* v = std::getenv("CGHIP_READBACK_DIRECT"); return !v || std::atoi(v) != 0; }();
+    const bool direct = direct_env && (flags & CGHIP_RENDER_READBACK) && !(flags & CGHIP_RENDER_FIELD_ROWS_ONLY) &&
+                        plan.segments.size() == 1 && plan.segments[0].gx0 == 0 && plan.segments[0].gy0 == 0 &&
+                        plan.segments[0].gx1 >= format->width && plan.segments[0].gy1 >= format->height;
     cghip_ticket* t = new cghip_ticket();
     t->dev = dev, t->stream = mixer->stream;
+    if (direct && (mixer->direct_frames++ & 1)) /* consecutive direct frames alternate between two streams: while one
+                                                   launch drains its stores over PCIe the next one composites */
+        t->stream = mixer->readback_stream;
     dev->tickets_live++;
     t->out_bytes = (size_t)format->width * format->height * 4 * (format->bits / 8);
     const size_t ops_only = plan.ops.size() * sizeof(KOp), mask_bytes = plan.masks.size() * sizeof(uint64_t);
@@ -641,7 +658,10 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
             return fail_hip(e__, #expr);                                                                               \
         }                                                                                                              \
     } while (0)
-    T_TRY(dev->dev_alloc(t->out_bytes, &t->d_out));
+    if (direct)
+        T_TRY(dev->pinned_alloc(t->out_bytes, &t->h_out));
+    else
+        T_TRY(dev->dev_alloc(t->out_bytes, &t->d_out));
     T_TRY(dev->dev_alloc(t->ops_bytes, &t->d_ops));
     T_TRY(dev->pinned_alloc(t->ops_bytes, &t->h_ops));
     if (!(flags & CGHIP_RENDER_UNTIMED)) /* one queue packet and one runtime call less per frame */
@@ -723,13 +743,15 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
         sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
         sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp ? 1 : 0;
         sp.mono = sg.mono;
-        T_HIP(cghip_launch_composite((const KOp*)t->d_ops + sg.first, sg.count, t->d_out, format->width, format->height,
+        T_HIP(cghip_launch_composite((const KOp*)t->d_ops + sg.first, sg.count, direct ? t->h_out : t->d_out, format->width, format->height,
                                      format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 + sg.ext : 0, &sp,
                                      sg.gx1 - sg.gx0, sg.gy1 - sg.gy0, t->stream));
         t->launches++;
     }
     T_HIP(hipEventRecord(t->ev_stop, t->stream));
-    if (flags & CGHIP_RENDER_READBACK) {
+    if (direct) {
+        T_HIP(hipEventRecord(t->ev_done, t->stream)); /* the launch's completion makes its stores to host memory visible */
+    } else if (flags & CGHIP_RENDER_READBACK) {
         /* The D2H rides the channel's readback stream, ordered after the frame's last launch by ev_stop: the
            compositor's stream is free for the next frame while this one crosses PCIe (the reference polls a fence every
            2 ms on its one GL thread, device.cpp:264-302). d_out and h_out belong to this ticket alone, and ev_done, which
@@ -900,7 +922,7 @@ int cghip_ticket_device_ptr(cghip_ticket* ticket, const void** device_ptr, size_
 {
     if (!ticket || !device_ptr)
         return fail(CGHIP_ERR_INVALID, "bad arguments");
-    *device_ptr = ticket->d_out;
+    *device_ptr = ticket->d_out ? ticket->d_out : ticket->h_out; /* direct readback: the pinned buffer, device-accessible */
     if (size)
         *size = ticket->out_bytes;
     return CGHIP_OK;
