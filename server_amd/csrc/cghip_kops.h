@@ -129,6 +129,9 @@ struct KSpill {
     int32_t  one_temp; /* touches RGBA1 but not RGBA2 (loads and stores included): the fast kernel with one temporary */
     int32_t  fused; /* the launch holds a fused blend-mode layer (KOp::fused): picks the general kernel's instance */
     int32_t  mono;  /* lean 4-pixels-per-lane launches: the KFetchBody every draw of the launch takes, or -1 */
+    int32_t  host_out; /* the frame buffer is pinned host memory (direct readback): plain stores, which the L2 merges
+                          into whole lines before they cross PCIe; frames that stay in HBM leave through non-temporal
+                          stores (written once, read by nobody on the GPU) */
 };
 
 struct KPlane {
