@@ -131,7 +131,8 @@ struct segment {
     bool     fast = false;         /* cghip_composite_fast, else cghip_composite */
     bool     full = false;         /* touches RGBA1 / RGBA2 */
     bool     fused = false;        /* holds a KOp::fused op */
-    bool     one_temp = false;     /* full, but RGBA2 is never touched, loaded or stored */
+    int      one_temp = 0;         /* full, but RGBA2 is never touched, loaded or stored: 1; and no op with a blend mode
+                                      (a MIX transition outside blend-mode layers): 2 */
     int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
     int      mono = -1;            /* fast, not full, ext 0: the one fetch body all its draws take (KSpill::mono), else -1 */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */

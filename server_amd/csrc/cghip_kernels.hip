@@ -2282,7 +2282,7 @@ DEV void fetch_rect16(const KOp& op, const HotG& g, int ax0, int ax1, int px0, i
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
-template <int BITS, bool FULL, int EXT, bool ONE = false, int MONO = -1> /* EXT: 0 aligned bodies only, 1 + sampled boxes,
+template <int BITS, bool FULL, int EXT, bool ONE = false, int MONO = -1, bool NOMODE = false> /* EXT: 0 aligned bodies only, 1 + sampled boxes,
                                                             2 + fused blend-mode layers. ONE (with FULL): the launch never
                                                             touches RGBA2 - a MIX transition outside blend-mode layers -
                                                             and the kernel does not hold it: 16 registers less per lane.
@@ -2369,7 +2369,7 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
         fetch_planar16r<HX, HY>(op, h, sx, SY, red_only, col);                                                         \
     else                                                                                                               \
         fetch_planar<16, HX, HY>(h, sx, SY, red_only, col);
-        switch (MONO >= 0 ? MONO : h.fetch_body) {
+        switch (MONO >= 0 ? ((FULL && h.fetch_body == FB_SURFACE) ? (int)FB_SURFACE : MONO) : h.fetch_body) {
             case FB_SURFACE:
                 if constexpr (FULL) {
                     if constexpr (ONE) {
@@ -2518,8 +2518,9 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                 switch (h.blend_body) {
                     case BB_RGBA_SIMPLE: fore4<0>(h, col, K0, K1, fo), store_rgba4<BITS>(fo, D); break;
                     case BB_RGBA_ONE_KEY: fore4<1>(h, col, K0, K1, fo), store_rgba4<BITS>(fo, D); break;
-                    case BB_MODE: /* a layer temporary composited with its blend mode */
-                        shade_blend_mode4<BITS>(BlendArgs{h.flags, h.local_key, h.layer_key, h.opacity, op.blend_mode}, col, D, K0, K1);
+                    case BB_MODE: /* a layer temporary composited with its blend mode (NOMODE: never planned for the instance) */
+                        if constexpr (!NOMODE)
+                            shade_blend_mode4<BITS>(BlendArgs{h.flags, h.local_key, h.layer_key, h.opacity, op.blend_mode}, col, D, K0, K1);
                         break;
                     case BB_FUSED: /* see the kernel without temporaries */
                         if constexpr (FUSED) {
@@ -2642,6 +2643,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONE_TEMP_WA
     const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
 {
     composite_fast_body<BITS, true, 0, true>(ops, nops, out, W, H, field_mode, sp);
+}
+#ifndef ONE_MONO_WAVES
+#define ONE_MONO_WAVES 5
+#endif
+/* ... and its one-format instance (see cghip_composite_fast_m below): MIX transitions between bgra sources */
+template <int BITS, int MONO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONE_MONO_WAVES))) void cghip_composite_fast_one_m(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, true, 0, true, MONO, true>(ops, nops, out, W, H, field_mode, sp);
 }
 /* Stacks of ONE source format - what a channel fed by one kind of input composites: 4:2:2 video layers with their
  * keys, an SDI rundown of uyvy inputs, stills and graphics in bgra. Every draw of such a launch takes the same fetch
@@ -2806,6 +2817,8 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
             hipLaunchKernelGGL((cghip_composite_fast_x<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!full && !sampled)
             hipLaunchKernelGGL((cghip_composite_fast<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+        else if (!sampled && s.one_temp == 2 && FB == 8 && s.mono == FB_PACKED8 && !cghip_g_no_mono)
+            hipLaunchKernelGGL((cghip_composite_fast_one_m<FB, FB_PACKED8>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!sampled && s.one_temp)
             hipLaunchKernelGGL((cghip_composite_fast_one<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
         else if (!sampled)

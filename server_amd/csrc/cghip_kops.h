@@ -126,7 +126,8 @@ struct KSpill {
     const uint64_t* masks;
     int32_t  ncols, nrows, nchunks, col_shift;
     int32_t  dense; /* every op is in every band (full-screen stacks): the table is not read */
-    int32_t  one_temp; /* touches RGBA1 but not RGBA2 (loads and stores included): the fast kernel with one temporary */
+    int32_t  one_temp; /* touches RGBA1 but not RGBA2 (loads and stores included): the fast kernel with one temporary;
+                          2: and no op with a blend mode (a plain MIX transition): the instance without the blend modes */
     int32_t  fused; /* the launch holds a fused blend-mode layer (KOp::fused): picks the general kernel's instance */
     int32_t  mono;  /* lean 4-pixels-per-lane launches: the KFetchBody every draw of the launch takes, or -1 */
     int32_t  host_out; /* the frame buffer is pinned host memory (direct readback): plain stores, which the L2 merges

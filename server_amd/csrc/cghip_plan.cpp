@@ -861,11 +861,11 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
                 sg.ext = std::max(sg.ext, o.fused ? 2 : (o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END) ? 1 : 0);
         }
         sg.mono = -1; /* one source format throughout: the kernel instance compiled for that fetch body alone */
-        if (sg.fast && !sg.full && sg.ext == 0) {
+        if (sg.fast && sg.ext == 0) { /* launches with temporaries: the format of the draws that fetch from planes */
             int body = -2;
             for (int i = sg.first; i < sg.first + sg.count; ++i) {
                 const KOp& o = ops[(size_t)i];
-                if (is_marker(o))
+                if (is_marker(o) || (sg.full && o.kind == KOP_DRAW_SURFACE))
                     continue;
                 body = (body == -2 || body == o.fetch_body) ? o.fetch_body : -1;
             }
@@ -875,7 +875,16 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         sg.store_mask = written & ~zero & later;
         if (si == 0)
             sg.store_mask |= surf_bit(KS_RGBA0); /* the first launch defines every pixel of the frame */
-        sg.one_temp = sg.full && !((touched | sg.load_mask | sg.store_mask) & surf_bit(KS_RGBA2));
+        sg.one_temp = sg.full && !((touched | sg.load_mask | sg.store_mask) & surf_bit(KS_RGBA2)) ? 1 : 0;
+        if (sg.one_temp) {
+            bool modes = false;
+            for (int i = sg.first; i < sg.first + sg.count; ++i) {
+                const KOp& o = ops[(size_t)i];
+                modes = modes || (!is_marker(o) && (o.blend_mode != 0 || o.fused || o.blend_body == BB_MODE || o.blend_body == BB_FUSED));
+            }
+            if (!modes)
+                sg.one_temp = 2;
+        }
         for (int r = 0; r < 2; ++r) { /* the key registers' buffers */
             const uint32_t bit = surf_bit(KS_KEY0 + r);
             sg.key_ld[r] = (sg.load_mask & bit) ? key_buf_of[r] : -1;

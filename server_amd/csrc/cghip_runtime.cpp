@@ -741,7 +741,7 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
         sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
-        sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp ? 1 : 0;
+        sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp;
         sp.mono = sg.mono;
         sp.host_out = direct ? 1 : 0;
         T_HIP(cghip_launch_composite((const KOp*)t->d_ops + sg.first, sg.count, direct ? t->h_out : t->d_out, format->width, format->height,
@@ -884,7 +884,7 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
         sp.load_mask = sg.load_mask, sp.store_mask = sg.store_mask;
         sp.gx0 = sg.gx0, sp.gy0 = sg.gy0;
         sp.masks = d_masks + sg.mask_off, sp.ncols = sg.ncols, sp.nrows = sg.nrows, sp.nchunks = sg.nchunks;
-        sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp ? 1 : 0;
+        sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp;
         sp.mono = sg.mono;
         sp.host_out = 0; /* the caller's device memory */
         NA_HIP(cghip_launch_composite((const KOp*)base + sg.first, sg.count, device_out, format->width, format->height,
