@@ -177,12 +177,16 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))
 
 
-def fuzz_box_scene(seed, bits=8, full=False):
+def fuzz_box_scene(seed, bits=8, full=False, mirror=False):
     """Random stacks with picture-in-picture boxes: axis-aligned layers at any scale and offset (sources of their own
     size, odd widths and tiny planes included) and 1:1 layers moved by whole pixels off the 4-pixel grid, between
     ordinary unit-scale layers. All of it is the 4-pixels-per-lane kernel's class since it samples boxes itself
-    (cghip_kernels.hip: fetch_rect8 / fetch_rect16); full=True puts some of the boxes into blend-mode layers."""
+    (cghip_kernels.hip: fetch_rect8 / fetch_rect16); full=True puts some of the boxes into blend-mode layers.
+    mirror=True flips most boxes horizontally and / or vertically (a negative fill_scale with the translation moved to
+    the box's other side: the usual flip in the reference; KF_AXIS admits it, s or t then DECREASE along the row or
+    column). The flips come from a generator of their own, so the unmirrored scenes of a seed are what they always were."""
     rng = random.Random(9000011 * seed + bits)
+    flips = random.Random(7919 * seed + 31 * bits + 5)
     W, H = rng.choice([(96, 64), (128, 36), (260, 50), (64, 90), (200, 40)])
     ops = []
     s = 12000 + 137 * seed
@@ -211,6 +215,13 @@ def fuzz_box_scene(seed, bits=8, full=False):
             if r() < 0.3:
                 t["crop_ul"], t["crop_lr"] = [round(rng.uniform(0, 0.3), 2), round(rng.uniform(0, 0.3), 2)], \
                                              [round(rng.uniform(0.6, 1.0), 2), round(rng.uniform(0.6, 1.0), 2)]
+            if mirror:
+                fx, fy = flips.random() < 0.6, flips.random() < 0.4
+                sc_, tr_ = t["fill_scale"], t["fill_translation"]
+                if fx:
+                    sc_[0], tr_[0] = -sc_[0], round(tr_[0] + sc_[0], 3)
+                if fy:
+                    sc_[1], tr_[1] = -sc_[1], round(tr_[1] + sc_[1], 3)
         elif mode == "shift":  # whole pixels, mostly not multiples of 4
             t["fill_translation"] = [rng.randint(-9, 9) / W, rng.randint(-5, 5) / H]
         if r() < 0.7:
@@ -234,7 +245,8 @@ def fuzz_box_scene(seed, bits=8, full=False):
         elif full and r() < 0.4:
             t["blend_mode"] = rng.choice(S.BLEND_NAMES)
         ops.append(S.layer(src, **t))
-    return S.scene("fuzzbox_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 0, 1, 2]))
+    return S.scene("fuzzbox%s_%d_%dbit" % ("m" if mirror else "", seed, bits), W, H, ops, bits=bits,
+                   field_mode=rng.choice([0, 0, 0, 1, 2]))
 
 
 def fuzz_nested_scene(seed, bits=8):

@@ -46,8 +46,8 @@ def test_oracle_matches_llvmpipe_on_box_scenes():
         pytest.skip("llvmpipe harness not available here")
     from fuzz_scenes import fuzz_box_scene
     worst = {"gt0": 0.0, "gt1": 0.0}
-    for seed in range(60):
-        sc = fuzz_box_scene(seed, 8, seed % 2 == 1)
+    for seed in range(100):  # 60 as they are + 40 with mirrored boxes (negative fill_scale)
+        sc = fuzz_box_scene(seed, 8, seed % 2 == 1) if seed < 60 else fuzz_box_scene(seed, 8, seed % 2 == 1, mirror=True)
         cache = {}
         a = S.run_oracle(sc, "cpu", cache)
         b = S.run_oracle(sc, "gl", cache)
@@ -58,7 +58,7 @@ def test_oracle_matches_llvmpipe_on_box_scenes():
         st = S.diff_stats(a, b)
         assert st["gt0"] <= 2e-3 and st["gt1"] <= 6e-4, (seed, st)  # same bound and reasons as above
         worst = {k: max(worst[k], st[k]) for k in worst}
-    print("oracle vs llvmpipe on 60 box scenes, worst:", worst)
+    print("oracle vs llvmpipe on 100 box scenes, worst:", worst)
 
 
 def _gl_field(sc, a, b):
@@ -298,6 +298,43 @@ def test_fast_kernel_samples_boxes_like_the_general_kernel(bits, full):
     finally:
         m.close()
     assert one_launch == 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
+def test_mirrored_boxes_match_the_general_kernel_and_the_oracle(bits):
+    """Boxes flipped horizontally and / or vertically (negative fill_scale): s or t decrease along the row or column,
+    which the sampled bodies' column taps, edge clamps and coverage must not care about. Same checks
+    as for the unmirrored boxes, 200 scenes per depth, every second one with blend-mode layers."""
+    import server_amd as A
+    from fuzz_scenes import fuzz_box_scene
+    m = A.Mixer(channel_id=7, gpu=0)
+    L = A.lib()
+    flipped = 0
+    try:
+        for seed in range(200):
+            sc = fuzz_box_scene(seed, bits, seed % 2 == 1, mirror=True)
+            flipped += sum(1 for o in sc["ops"] if o[0] == "push" and min(o[1].get("fill_scale", [1, 1])) < 0)
+            cache = {}
+            fast = S.run_product(sc, mixer=m, planes_cache=cache)
+            L.cghip_debug_force_general_kernel(1)
+            try:
+                general = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_force_general_kernel(0)
+            sd = S.diff_stats(fast, general)
+            assert sd["max"] == 0 if bits == 8 else (sd["gt2"] <= 1e-3 and sd["gt0"] <= 2e-2), (seed, sd)
+            ref = S.run_oracle(sc, "cpu", cache)
+            st = S.diff_stats(fast, ref)
+            if bits == 8:
+                pow_used = any(o[0] == "push" and o[1].get("levels_gamma", 1.0) != 1.0 for o in sc["ops"])
+                assert (st["max"] <= 1 and st["gt0"] <= 1e-4) if pow_used else st["max"] == 0, (seed, st)
+            else:
+                st = P16.check(sc, fast, ref, cache)
+                assert st["max_outside_amplifying"] <= P16.LIMIT, (seed, st)
+    finally:
+        m.close()
+    assert flipped > 150, flipped
 
 
 @pytest.mark.gpu

@@ -283,8 +283,8 @@ def test_box_fuzz_scenes_are_planned_for_the_fast_kernels_sampled_bodies(bits):
     test over these scenes (tests/test_fuzz.py) only means something if the planner sends them there."""
     from fuzz_scenes import fuzz_box_scene
     n_sampled = n_axis = n_unit = 0
-    for seed in range(100):
-        sc = fuzz_box_scene(seed, bits, seed % 2 == 1)
+    for seed in range(160):  # 100 as they are + 60 with mirrored boxes (negative fill_scale: KF_AXIS admits them)
+        sc = fuzz_box_scene(seed, bits, seed % 2 == 1, mirror=seed >= 100)
         _d, _s, ops, _full = product_plan(sc)
         assert K.last_plan_fast or not ops, (seed, [(o.kind, o.fast_class, hex(o.flags)) for o in ops])
         for o in ops:
