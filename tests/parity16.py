@@ -85,7 +85,8 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
     down together. The kernels of 16-bit frames evaluate the shader with fused multiply-adds and reciprocal
     multiplies (server_amd/csrc/cghip_kernels.hip: divf), a few 1e-7 away from the exact sequence, so a few per cent of
     their stores round to the neighbouring code; a later draw whose blend mode divides by alpha or whose contrast
-    exceeds 2 turns that one LSB16 into three. The draw-by-draw rounding itself is kept. (Rounds 1 - 2 flipped stores
+    exceeds 2 turns that one LSB16 into three. The draw-by-draw rounding itself is kept. For these probes a pixel counts
+    as amplifying when the oracle moves by `limit` or more (see the code). (Rounds 1 - 2 flipped stores
     at random with four seeds: a statistical probe that could miss a pixel. This one cannot miss what ONE draw's LSB
     is worth.)"""
     from oracle import oracle as O
@@ -114,10 +115,16 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
         for _name, fn in perturbations().items():
             mask |= _moved(sc, _perturbed(cache, fn), base, limit)
     if tier >= 3:
+        # A store one code off is a difference the relaxed kernels legitimately have at an INTERMEDIATE target; their last
+        # draw rounds on its own on top of that. So a pixel amplifies already when one flipped store moves the oracle's
+        # output by `limit` (2 = a gain of 1.5 .. 2.5), not only by more: 2 from the flip + 1 from the final rounding is
+        # the 3 that two pixels in 100 000 further scenes showed (tests/gpu_parity16_hunt.py, seeds 10 000 - 30 000:
+        # fuzzfast_14893 and fuzzbox_28118, every single-draw flip worth exactly 2 there).
+        flip_limit = limit - 1
         for seed in (0xFFFFFFFF, 0xFFFFFFFE):  # every store of every draw up / down
             L.cpuref_set_store_flip(seed)
             try:
-                mask |= _moved(sc, cache, base, limit)
+                mask |= _moved(sc, cache, base, flip_limit)
             finally:
                 L.cpuref_set_store_flip(0)
         L.cpuref_reset_draw_count()
@@ -131,7 +138,7 @@ def amplifying_pixels(sc, cache, ref, limit=LIMIT, tier=1):
             for draw in range(1, ndraws + 1):
                 for p in patterns:
                     L.cpuref_set_store_flip_draw(draw, *p)
-                    mask |= _moved(sc, cache, base, limit)
+                    mask |= _moved(sc, cache, base, flip_limit)
         finally:
             L.cpuref_set_store_flip_draw(0, 0, 0, 0, 0)
     return mask
