@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import scenes as S
 import server_amd as A
-from fuzz_scenes import fuzz_scene, fuzz_fast_scene, fuzz_box_scene
+from fuzz_scenes import fuzz_scene, fuzz_fast_scene, fuzz_box_scene, fuzz_nested_scene
 
 lo, hi = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 2500
 m = A.Mixer(channel_id=9, gpu=0)
@@ -16,7 +16,8 @@ L = A.lib()
 bad = 0
 t0 = time.time()
 for seed in range(lo, hi):
-    for sc in (fuzz_box_scene(seed, 8, seed % 2 == 1), fuzz_fast_scene(seed, 8, seed % 2 == 0), fuzz_scene(seed, 8)):
+    for sc in (fuzz_box_scene(seed, 8, seed % 2 == 1), fuzz_fast_scene(seed, 8, seed % 2 == 0), fuzz_scene(seed, 8),
+               fuzz_box_scene(seed, 8, seed % 2 == 0, mirror=True), fuzz_nested_scene(seed, 8)):  # the last two: round 3
         cache = {}
         got = S.run_product(sc, mixer=m, planes_cache=cache)
         L.cghip_debug_force_general_kernel(1)
