@@ -396,8 +396,12 @@ def main():
                 "channels_per_gpu": ncha, "frames_in_flight": 2, "settle_s": args.settle, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": {"config4": "cghip_composite_fast_one<%d>", "config2": "cghip_composite<%d, false, true>"}.get(
-                             args.workload, "cghip_composite_fast<%d>") % scene["bits"],
+                         # the kernel instance the planner's launch of this workload runs (cghip_kernels.hip: launcher;
+                         # the same names are in profiles/r03_*_kernel_stats.csv)
+                         "kernel": {"config4": "cghip_composite_fast_one_m<8, 1>", "config2": "cghip_composite<8, false, true>",
+                                    "config1": "cghip_composite_fast_m<8, 1>", "config3_8bit": "cghip_composite_fast<8>",
+                                    "config3_16bit": "cghip_composite_fast_m<16, 8>"}.get(
+                             args.workload, "cghip_composite_fast<%d>" % scene["bits"]),
                          "avg_kernel_ms": avg_kernel_ms, "launch_ms": launch_stats,
                          "algorithmic_bytes_per_launch": alg_bytes, "valu": valu},
             "cpu_baseline": cpu,
