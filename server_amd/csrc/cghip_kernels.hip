@@ -1962,7 +1962,6 @@ DEV void store_rgba4(const Fore& o, f4 S[4])
     }
     static_for<0, 4>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        if (BITS == 16 || opaque_s(1)) /* PX_BRANCH in the 8-bit build: config 3 at 8 bits 0.252 -> 0.248 ms; nothing at 16 */
         S[i] = f4{quantize<BITS>(o.f[i].x + o.ia[i] * S[i].x), quantize<BITS>(o.f[i].y + o.ia[i] * S[i].y),
                   quantize<BITS>(o.f[i].z + o.ia[i] * S[i].z), quantize<BITS>(o.f[i].w + o.ia[i] * S[i].w)};
     });
