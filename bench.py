@@ -398,7 +398,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          # the kernel instance the planner's launch of this workload runs (cghip_kernels.hip: launcher;
                          # the same names are in profiles/r03_*_kernel_stats.csv)
-                         "kernel": {"config4": "cghip_composite_fast_one_m<8, 1>", "config2": "cghip_composite<8, false, true>",
+                         "kernel": {"config4": "cghip_composite_fast_p<8>", "config2": "cghip_composite<8, false, true>",
                                     "config1": "cghip_composite_fast_m<8, 1>", "config3_8bit": "cghip_composite_fast<8>",
                                     "config3_16bit": "cghip_composite_fast_m<16, 8>"}.get(
                              args.workload, "cghip_composite_fast<%d>" % scene["bits"]),

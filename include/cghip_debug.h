@@ -57,6 +57,10 @@ void cghip_debug_plain_tiles(int on);
 /* Launches whose draws all take one fetch body run a kernel instance compiled for that body alone
  * (cghip_composite_fast_m); on = they run the kernel with all bodies, so tests can compare the two bit for bit. */
 void cghip_debug_no_mono_kernels(int on);
+/* A MIX transition between aligned unit-scale sources (CLEAR, two items into the mix texture, its composite) is planned
+ * as one step of the lean 4-pixels-per-lane kernel when the frame needs no temporary otherwise (cghip_plan.cpp:
+ * fuse_mix_pairs); on = it stays four ops in the kernels that hold a temporary, so tests can compare bit for bit. */
+void cghip_debug_no_mix_fusion(int on);
 
 #ifdef __cplusplus
 }

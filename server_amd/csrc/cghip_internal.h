@@ -133,6 +133,7 @@ struct segment {
     bool     fused = false;        /* holds a KOp::fused op */
     int      one_temp = 0;         /* full, but RGBA2 is never touched, loaded or stored: 1; and no op with a blend mode
                                       (a MIX transition outside blend-mode layers): 2 */
+    bool     mix_pairs = false;    /* holds fused MIX pairs (BB_MIX_HEAD) */
     int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
     int      mono = -1;            /* fast, not full, ext 0: the one fetch body all its draws take (KSpill::mono), else -1 */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */
@@ -152,6 +153,7 @@ struct frame_plan {
     uint32_t         spill_mask = 0; /* KSurf bits (RGBA1, RGBA2) that need a buffer in HBM between launches */
     int              n_key_bufs = 0; /* 1-channel buffers the launches hand key surfaces over through */
     bool             full = false; /* needs the RGBA1/RGBA2 register surfaces */
+    bool             mix_pairs = false; /* holds fused MIX pairs (BB_MIX_HEAD): a frame of the fast class without temporaries */
     bool             fast = false; /* every draw qualifies for cghip_composite_fast (then there is one segment) */
     std::vector<cghip_plane*> planes; /* every plane referenced by an emitted op */
     std::vector<uint64_t>     masks;  /* the segments' op masks; uploaded behind the ops */

@@ -2281,7 +2281,72 @@ DEV void fetch_rect16(const KOp& op, const HotG& g, int ax0, int ax1, int px0, i
 /* FULL adds the two RGBA temporaries (layer texture for non-normal blend modes, mix texture for MIX transitions:
  * image_mixer.cpp:128,187) as 32 more registers per lane, composite draws of them (KOP_DRAW_SURFACE, any blend mode,
  * either keyer) and item draws into them. 128 VGPRs: four waves per SIMD. */
-template <int BITS, bool FULL, int EXT, bool ONE = false, int MONO = -1, bool NOMODE = false> /* EXT: 0 aligned bodies only, 1 + sampled boxes,
+/* The aligned unit-scale fetch bodies and the adjustments as functions, for the step of a fused MIX pair
+ * (composite_fast_body, MIXP), which runs them twice. The op loop itself keeps its inline switch: as a function called
+ * from there the bodies were allocated differently and the headline frame paid for it. */
+template <int BITS>
+DEV void fetch_aligned(const KOp& op, const HotOp& h, int px0, int y, f4 col[4])
+{
+    const int  sx = px0 + h.unit_dx, sy = opaque_s(y + h.unit_dy);
+    const bool red_only = h.flags & KF_RED_ONLY;
+#define PLANAR16(HX, HY)                                                                                               \
+    if constexpr (BITS == 16)                                                                                          \
+        fetch_planar16r<HX, HY>(op, h, sx, sy, red_only, col);                                                         \
+    else                                                                                                               \
+        fetch_planar<16, HX, HY>(h, sx, sy, red_only, col);
+    switch (h.fetch_body) {
+        case FB_UYVY8: fetch_uyvy8(h, sx, sy, col); break;
+        case FB_BYTES8: fetch_bytes8(h, sx, sy, col); break;
+        case FB_PACKED8: fetch_packed<8>(h, sx, sy, col); break;
+        case FB_PACKED16: fetch_packed<16>(h, sx, sy, col); break;
+        case FB_PLANAR8 + 0: fetch_planar<8, 0, 0>(h, sx, sy, red_only, col); break;
+        case FB_PLANAR8 + 1: fetch_planar<8, 1, 0>(h, sx, sy, red_only, col); break;
+        case FB_PLANAR8 + 2: fetch_planar<8, 0, 1>(h, sx, sy, red_only, col); break;
+        case FB_PLANAR8 + 3: fetch_planar<8, 1, 1>(h, sx, sy, red_only, col); break;
+        case FB_PLANAR16 + 0: PLANAR16(0, 0) break;
+        case FB_PLANAR16 + 1: PLANAR16(1, 0) break;
+        case FB_PLANAR16 + 2: PLANAR16(0, 1) break;
+        default: PLANAR16(1, 1) break;
+    }
+#undef PLANAR16
+}
+/* shader.frag:526-531 on a lane's four pixels, then the box edge inside the lane (KF_EDGE) */
+DEV void adjust4(const KOp& op, const HotOp& h, int px0, f4 col[4])
+{
+    if (h.flags & KF_CHROMA) {
+        const ChromaV cp(op);
+        const bool    mask = cp.flags & KF_CHROMA_MASK, plain = !(opaque_s((int)cp.flags) & KF_CHROMA_MASK);
+        if constexpr (RXF) {
+            const ChromaRx k(cp);
+            if (mask)
+                static_for<0, 4>([&](auto I) { col[decltype(I)::value] = chroma_key_relaxed<true>(col[decltype(I)::value], k); });
+            if (plain)
+                static_for<0, 4>([&](auto I) { PX_BRANCH col[decltype(I)::value] = chroma_key_relaxed<false>(col[decltype(I)::value], k); });
+        } else {
+            if (mask)
+                static_for<0, 4>([&](auto I) { col[decltype(I)::value] = chroma_key<false, 1>(col[decltype(I)::value], cp); });
+            if (plain)
+                static_for<0, 4>([&](auto I) { PX_BRANCH col[decltype(I)::value] = chroma_key<false, 0>(col[decltype(I)::value], cp); });
+        }
+    }
+    if (h.flags & KF_LEVELS) {
+        const LevelsV lp(op);
+        levels12<RXF>(col, lp);
+    }
+    if (h.flags & KF_CSB) {
+        const CsbV bp(op);
+        static_for<0, 4>([&](auto I) { csb<RXF>(col[decltype(I)::value], bp); });
+    }
+    if (h.flags & KF_EDGE) {
+        const uint32_t span = (uint32_t)(h.ax1 - h.ax0);
+        static_for<0, 4>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            col[i] = sel4((uint32_t)(px0 + i - h.ax0) < span, col[i], f4{0, 0, 0, 0});
+        });
+    }
+}
+
+template <int BITS, bool FULL, int EXT, bool ONE = false, int MONO = -1, bool NOMODE = false, bool MIXP = false> /* EXT: 0 aligned bodies only, 1 + sampled boxes,
                                                             2 + fused blend-mode layers. ONE (with FULL): the launch never
                                                             touches RGBA2 - a MIX transition outside blend-mode layers -
                                                             and the kernel does not hold it: 16 registers less per lane.
@@ -2328,11 +2393,21 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
     /* only the ops that can touch this wave's band of the frame (KSpill::masks, host: op_masks) */
     const int mcol = __builtin_amdgcn_readfirstlane(px0) >> sp.col_shift, mrow = y >> 2;
     const int mstride = sp.ncols + sp.nrows;
+    int       mix_skip = 0; /* MIXP: ops still to pass over behind a BB_MIX_HEAD */
+    (void)mix_skip;
     for (int chunk = 0; chunk < sp.nchunks && row_live; ++chunk)
     for (uint64_t todo = band_ops(sp, chunk, mstride, mcol, mrow, nops); todo != 0; todo &= todo - 1) {
         const int   n   = chunk * 64 + __builtin_ctzll(todo);
         const KOp&  op  = ops[__builtin_amdgcn_readfirstlane(n)]; /* n is uniform; say so (see dispatch_mode) */
         const HotOp h   = load_hot(op);
+        if constexpr (MIXP) { /* the two ops behind a BB_MIX_HEAD were run by its step (wave-uniform) */
+            if (mix_skip > 0) {
+                --mix_skip;
+                continue;
+            }
+            if (h.kind == KOP_DRAW_PLANES && h.blend_body == BB_MIX_HEAD)
+                mix_skip = 2;
+        }
         const bool  clr = h.kind == KOP_CLEAR;
         const bool  clr0 = clr & (h.dst == KS_KEY0), clr1 = clr & (h.dst == KS_KEY1);
         if (clr) { /* wave-uniform; the selects stay inside so that draws do not pay for them */
@@ -2352,6 +2427,37 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
            multiples of 4 (a lane is all in or all out) unless the op carries KF_EDGE, see below. */
         if (clr | !((y >= h.y0) & (y < h.y1) & (px0 > h.x0 - P) & (px0 < h.x1)))
             continue;
+        if constexpr (MIXP) {
+            if (h.blend_body == BB_MIX_HEAD) {
+                /* A fused MIX pair (cghip_plan.cpp: fuse_mix_pairs): this op and the next are the two items drawn into
+                   the cleared mix texture, the one after composites it (image_mixer.cpp:187-225). The texture T lives in
+                   this step only. Each item: fore colour, then T = store(fore + ia * T) - store_rgba4 over the zero T
+                   for the first, exactly what the kernels with a temporary do op by op. */
+                f4 T[P];
+                static_for<0, P>([&](auto I) { T[decltype(I)::value] = f4{0, 0, 0, 0}; });
+                auto item = [&](const KOp& o, const HotOp& g) {
+                    f4 c[P];
+                    fetch_aligned<BITS>(o, g, px0, y, c);
+                    adjust4(o, g, px0, c);
+                    Fore fo;
+                    fore4<2>(g, c, K0, K1, fo);
+                    store_rgba4<BITS>(fo, T);
+                };
+                item(op, h);
+                const KOp& opb = ops[__builtin_amdgcn_readfirstlane(n + 1)];
+                item(opb, load_hot(opb));
+                const KOp&  ops_ = ops[__builtin_amdgcn_readfirstlane(n + 2)];
+                const HotOp hs   = load_hot(ops_);
+                Fore        fo;
+                switch (hs.blend_body) {
+                    case BB_RGBA_SIMPLE: fore4<0>(hs, T, K0, K1, fo); break;
+                    case BB_RGBA_ONE_KEY: fore4<1>(hs, T, K0, K1, fo); break;
+                    default: fore4<2>(hs, T, K0, K1, fo); break;
+                }
+                store_rgba4<BITS>(fo, S);
+                continue;
+            }
+        }
         /* Source colour: the body the planner picked (KOp::fetch_body). Each body starts from an OPAQUE copy of the
            source row: left to itself the compiler hoists the row-address arithmetic of all ten bodies in front of the
            switch, where every op and wave paid ~90 scalar instructions for bodies it does not run - and the scalar
@@ -2653,6 +2759,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONE_MONO_WA
 {
     composite_fast_body<BITS, true, 0, true, MONO, true>(ops, nops, out, W, H, field_mode, sp);
 }
+/* The lean kernel with the step for fused MIX pairs (BB_MIX_HEAD, KSpill::mix_pairs): crossfades between unit-scale
+ * sources without a temporary. A kernel of its own: the step's registers (the mix texture of four pixels) would cost
+ * every other launch of the lean kernel its seventh wave. */
+#ifndef MIX_WAVES
+#define MIX_WAVES 5
+#endif
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIX_WAVES))) void cghip_composite_fast_p(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, false, 0, false, -1, false, true>(ops, nops, out, W, H, field_mode, sp);
+}
 /* Stacks of ONE source format - what a channel fed by one kind of input composites: 4:2:2 video layers with their
  * keys, an SDI rundown of uyvy inputs, stills and graphics in bgra. Every draw of such a launch takes the same fetch
  * body (KSpill::mono, cghip_plan.cpp), and an instance of the lean kernel compiled for that body alone has no switch
@@ -2794,6 +2912,12 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
         const bool sampled = fast >= 2; /* the launch holds a draw with a sampled fetch body (2) or a fused layer (3) */
 #define LAUNCH_MONO(body)                                                                                              \
     hipLaunchKernelGGL((cghip_composite_fast_m<FB, body>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s)
+        if (s.mix_pairs) { /* planned only for launches of aligned draws without temporaries */
+            if (full || sampled)
+                return hipErrorInvalidValue;
+            hipLaunchKernelGGL((cghip_composite_fast_p<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            return hipGetLastError();
+        }
         const int mono = (!full && !sampled && !cghip_g_no_mono) ? s.mono : -1;
         bool      launched = true; /* the instances of this object's frame depth only; measured on the same box against
                                       the kernel with all bodies (tests/gpu_ab.sh): packed 8-bit stacks -7 % (config 1

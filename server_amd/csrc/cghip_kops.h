@@ -78,7 +78,11 @@ enum KBlendBody : int32_t {
     BB_KEY_SIMPLE   = 3, /* into a key surface */
     BB_KEY_GENERAL  = 4,
     BB_MODE         = 5, /* a temporary composited with a blend mode */
-    BB_FUSED        = 6  /* KOp::fused: the item over zero, its UNORM store, the composite's blend mode */
+    BB_FUSED        = 6, /* KOp::fused: the item over zero, its UNORM store, the composite's blend mode */
+    BB_MIX_HEAD     = 7  /* the first item of a fused MIX pair (cghip_plan.cpp: fuse_mix_pairs): this op, the next (the second
+                            item) and the one after (the composite of the mix texture) are ONE step of the kernel, the mix
+                            texture lives in registers of that step only. Launches with such ops run
+                            cghip_composite_fast_p (KSpill::mix_pairs) */
 };
 
 /* How cghip_composite samples a KOP_DRAW_PLANES source (host classification, cghip_plan.cpp). The two common
@@ -130,6 +134,7 @@ struct KSpill {
                           2: and no op with a blend mode (a plain MIX transition): the instance without the blend modes */
     int32_t  fused; /* the launch holds a fused blend-mode layer (KOp::fused): picks the general kernel's instance */
     int32_t  mono;  /* lean 4-pixels-per-lane launches: the KFetchBody every draw of the launch takes, or -1 */
+    int32_t  mix_pairs; /* the launch holds BB_MIX_HEAD ops: the lean kernel's instance that knows them */
     int32_t  host_out; /* the frame buffer is pinned host memory (direct readback): plain stores, which the L2 merges
                           into whole lines before they cross PCIe; frames that stay in HBM leave through non-temporal
                           stores (written once, read by nobody on the GPU) */

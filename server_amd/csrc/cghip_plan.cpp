@@ -860,6 +860,9 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             if (o.kind == KOP_DRAW_PLANES)
                 sg.ext = std::max(sg.ext, o.fused ? 2 : (o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END) ? 1 : 0);
         }
+        sg.mix_pairs = false;
+        for (int i = sg.first; i < sg.first + sg.count; ++i)
+            sg.mix_pairs = sg.mix_pairs || (ops[(size_t)i].kind == KOP_DRAW_PLANES && ops[(size_t)i].blend_body == BB_MIX_HEAD);
         sg.mono = -1; /* one source format throughout: the kernel instance compiled for that fetch body alone */
         if (sg.fast && sg.ext == 0) { /* launches with temporaries: the format of the draws that fetch from planes */
             int body = -2;
@@ -1045,6 +1048,82 @@ static void fuse_layers(const cghip_format& fmt, frame_plan* out)
         if (!is_marker(o) && o.fast_class == FC_NONE)
             out->fast = false;
     }
+}
+
+/* A MIX transition outside blend-mode layers - two is_mix items drawn into the cleared mix texture with the additive
+ * keyer, the texture composited over the frame (image_mixer.cpp:187-225; BASELINE config 4, every crossfade of a
+ * rundown) - is four ops: CLEAR T, A -> T, B -> T, T -> frame. With T in registers the frame needs the kernel variants
+ * that hold a temporary (96 - 128 registers, 4 - 5 waves per SIMD). Fused, the three draws are ONE step of the lean
+ * kernel: A over zero, its UNORM store, B added, its UNORM store, the result composited - the same arithmetic in the
+ * same order (test hook cghip_debug_no_mix_fusion; tests/test_fuzz.py compares the two plans bit for bit) with the
+ * texture in registers of that step alone. Only for frames that are the 4-pixels-per-lane class throughout and need no
+ * temporary once their pairs are fused; both items aligned unit-scale draws of one box, the composite plain. */
+static int g_no_mix_fusion = 0;
+static void fuse_mix_pairs(const cghip_format& fmt, frame_plan* out)
+{
+    if (g_no_mix_fusion || g_force_general || !out->fast || !out->full)
+        return;
+    const std::vector<KOp>& ops = out->ops;
+    const int               n   = (int)ops.size();
+    for (const KOp& o : ops) /* the step exists in the lean kernel of aligned draws only (cghip_composite_fast_p) */
+        if (!is_marker(o) && (o.fused || (o.kind == KOP_DRAW_PLANES && o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END)))
+            return;
+    std::vector<int>        head; /* index of the CLEAR of every pair that qualifies */
+    std::vector<char>       in_pair((size_t)n, 0);
+    for (int c = 0; c + 3 < n; ++c) {
+        const KOp &C = ops[(size_t)c], &A = ops[(size_t)c + 1], &B = ops[(size_t)c + 2], &S = ops[(size_t)c + 3];
+        if (C.kind != KOP_CLEAR || (C.dst != KS_RGBA1 && C.dst != KS_RGBA2))
+            continue;
+        const int T = C.dst;
+        auto item = [&](const KOp& o) {
+            return o.kind == KOP_DRAW_PLANES && o.dst == T && o.blend_mode == 0 && !o.fused &&
+                   (o.fast_class == FC_PACKED || o.fast_class == FC_PLANAR || o.fast_class == FC_UYVY || o.fast_class == FC_BYTES) &&
+                   !(refs_of(o) & ~(surf_bit(T) | surf_bit(KS_KEY0) | surf_bit(KS_KEY1)));
+        };
+        if (!item(A) || !item(B) || A.x0 != B.x0 || A.y0 != B.y0 || A.x1 != B.x1 || A.y1 != B.y1)
+            continue;
+        if (S.kind != KOP_DRAW_SURFACE || S.src_surface != T || S.dst != KS_RGBA0 || S.blend_mode != 0 || S.fused ||
+            S.fast_class != FC_SURFACE || (S.flags & (KF_LEVELS | KF_CSB | KF_CHROMA | KF_INVERT)))
+            continue;
+        if (S.x0 != (A.x0 & ~3) || S.x1 != std::min(fmt.width, (A.x1 + 3) & ~3) || S.y0 != A.y0 || S.y1 != A.y1)
+            continue; /* the composite's lanes are the items' lanes */
+        bool dead = true; /* nothing looks at T afterwards before it is cleared again */
+        for (int k = c + 4; k < n && dead; ++k) {
+            const KOp& o = ops[(size_t)k];
+            if (o.kind == KOP_CLEAR && o.dst == T)
+                break;
+            dead = !(refs_of(o) & surf_bit(T));
+        }
+        if (!dead)
+            continue;
+        head.push_back(c);
+        in_pair[(size_t)c] = in_pair[(size_t)c + 1] = in_pair[(size_t)c + 2] = in_pair[(size_t)c + 3] = 1;
+        c += 3;
+    }
+    if (head.empty())
+        return;
+    for (int i = 0; i < n; ++i) /* all or nothing: a temporary left anywhere keeps the frame in the kernels that hold one */
+        if (!in_pair[(size_t)i] && (refs_of(ops[(size_t)i]) & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))))
+            return;
+    std::vector<KOp> fused;
+    fused.reserve((size_t)n);
+    size_t h = 0;
+    for (int i = 0; i < n; ++i) {
+        if (h < head.size() && i == head[h]) {
+            KOp A = ops[(size_t)i + 1], B = ops[(size_t)i + 2], S = ops[(size_t)i + 3];
+            A.blend_body = BB_MIX_HEAD;
+            A.dst = B.dst = KS_RGBA0; /* what the step as a whole writes */
+            S.src_surface = KS_RGBA0; /* never read as a source: the step hands the texture over in registers */
+            fused.push_back(A), fused.push_back(B), fused.push_back(S);
+            i += 3;
+            ++h;
+            continue;
+        }
+        fused.push_back(ops[(size_t)i]);
+    }
+    out->ops.swap(fused);
+    out->full = false;
+    out->mix_pairs = true;
 }
 
 /* Per launch: which of its ops can touch which band of the frame. The kernels used to walk the whole op list in
@@ -1264,6 +1343,7 @@ int plan_frame(const cghip_format* fmt, const cghip_surface* surfaces, int nsurf
             out->fast = false;
     drop_hidden_ops(*fmt, out);
     fuse_layers(*fmt, out);
+    fuse_mix_pairs(*fmt, out);
     split_into_segments(*fmt, out);
     op_masks(*fmt, out);
     return CGHIP_OK;
@@ -1303,6 +1383,8 @@ extern "C" void cghip_debug_generic_sampling(int on) { cghip::g_generic_sampling
 extern "C" void cghip_debug_no_sampled_fast(int on) { cghip::g_no_sampled_fast = on; }
 /* blend-mode layers with one item stay three ops (CLEAR, item, composite) in launches of the general kernel */
 extern "C" void cghip_debug_no_layer_fusion(int on) { cghip::g_no_layer_fusion = on; }
+/* MIX pairs stay four ops (CLEAR, two items, composite) in the kernels that hold a temporary */
+extern "C" void cghip_debug_no_mix_fusion(int on) { cghip::g_no_mix_fusion = on; }
 extern "C" void cghip_debug_keep_hidden_ops(int on) { cghip::g_keep_hidden_ops = on; }
 extern "C" void cghip_debug_full_frame_composites(int on) { cghip::g_full_frame_composites = on; }
 extern "C" void cghip_debug_max_segments(int n) { cghip::g_max_segments = n >= 1 ? n : 8; }

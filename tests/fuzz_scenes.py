@@ -177,6 +177,53 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))
 
 
+def fuzz_mix_scene(seed, bits=8):
+    """Unit-scale stacks without blend-mode layers in which about every second fill layer is a MIX transition (two is_mix
+    items in one layer, image_mixer.cpp:187-225): what the planner fuses into one step of the lean kernel
+    (cghip_plan.cpp: fuse_mix_pairs). The stack is fuzz_fast_scene's (keys, every adjustment, crops, clips, field modes);
+    the second item of a pair is another source of the frame's size, sometimes with adjustments of its own."""
+    base = fuzz_fast_scene(seed, bits, False)
+    rng = random.Random(6000011 * seed + bits + 3)
+    W, H = base["width"], base["height"]
+    ops = []
+    flat = base["ops"]  # scene() flattened the layers: without blend-mode layers and MIX pairs they are push / visit / pop triples
+    assert len(flat) % 3 == 0 and all(flat[k][0] == ("push", "visit", "pop")[k % 3] for k in range(len(flat)))
+    for i, lay in enumerate([flat[k:k + 3] for k in range(0, len(flat), 3)]):
+        t = lay[0][1]
+        if t.get("is_key") or t.get("invert") or rng.random() < 0.5:
+            ops.append(lay)
+            continue
+        d = rng.choice([0.5, 0.25, round(rng.random(), 2)])
+        f = rng.choice(["bgra", "argb", "ycbcr422", "ycbcr420", "ycbcra444"] + (["uyvy", "gray"] if bits == 8 else []))
+        sd = 31000 + 17 * seed + i
+        if f == "uyvy":
+            other = S.frame("uyvy", [(W, H, 2, "video", sd)], bits)
+        elif f == "gray":
+            other = S.frame("gray", [(W, H, 1, "smooth", sd)], bits)
+        elif f in ("bgra", "argb"):
+            other = S.frame(f, [(W, H, 4, rng.choice(["premul", "noise"]), sd)], bits)
+        else:
+            other = S.ycbcr(W, H, f[-3:], "video", sd, bits=bits, alpha=f.startswith("ycbcra"))
+        lt = {k: v for k, v in t.items() if k in ("opacity", "layer_depth")}
+        if rng.random() < 0.5:
+            lt.pop("opacity", None)
+        it = {k: v for k, v in t.items() if k not in ("opacity", "layer_depth")}
+        ot = {}
+        if rng.random() < 0.8:  # the same box as the first item (crop, clip, the colour producer's rectangle): what fuses
+            ot.update({k: v for k, v in t.items() if k in ("crop_ul", "crop_lr", "clip_translation", "clip_scale",
+                                                            "fill_translation", "fill_scale")})
+        if rng.random() < 0.3:
+            ot.update(levels_min_input=0.05, levels_max_input=0.9, levels_gamma=rng.choice([1.0, 1.2]), levels_min_output=0.0,
+                      levels_max_output=1.0)
+        if rng.random() < 0.15:
+            ot.update(brightness=1.1, saturation=0.8, contrast=1.2)
+        ops.append([("push", lt),
+                    ("push", dict(it, is_mix=1, opacity=round(1.0 - d, 2))), ("visit", lay[1][1]), ("pop",),
+                    ("push", dict(ot, is_mix=1, opacity=d)), ("visit", other), ("pop",),
+                    ("pop",)])
+    return S.scene("fuzzmix_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=base["field_mode"])
+
+
 def fuzz_box_scene(seed, bits=8, full=False, mirror=False):
     """Random stacks with picture-in-picture boxes: axis-aligned layers at any scale and offset (sources of their own
     size, odd widths and tiny planes included) and 1:1 layers moved by whole pixels off the 4-pixel grid, between

@@ -339,6 +339,59 @@ def test_mirrored_boxes_match_the_general_kernel_and_the_oracle(bits):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bits", [8, 16])
+def test_fused_mix_pairs_equal_the_four_draws(bits):
+    """A MIX transition outside blend-mode layers (CLEAR, two items into the mix texture, its composite) is ONE step of
+    the lean 4-pixels-per-lane kernel when the frame needs no temporary otherwise (cghip_plan.cpp: fuse_mix_pairs,
+    cghip_composite_fast_p): same arithmetic in the same order as the four ops in the kernels that hold a temporary.
+    300 random stacks with such pairs and BASELINE config 4: bit-identical in 8-bit frames (to the neighbouring code in
+    16-bit frames, where two kernels contract different multiply-adds), and against the oracle as everywhere else."""
+    import server_amd as A
+    from fuzz_scenes import fuzz_mix_scene
+    m = A.Mixer(channel_id=8, gpu=0)
+    L = A.lib()
+    try:
+        for sc in [fuzz_mix_scene(seed, bits) for seed in range(300)] + ([S.config4()] if bits == 8 else []):
+            cache = {}
+            fused = S.run_product(sc, mixer=m, planes_cache=cache)
+            L.cghip_debug_no_mix_fusion(1)
+            try:
+                four = S.run_product(sc, mixer=m, planes_cache=cache)
+            finally:
+                L.cghip_debug_no_mix_fusion(0)
+            sd = S.diff_stats(fused, four)
+            assert sd["max"] == 0 if bits == 8 else (sd["gt2"] <= 1e-3 and sd["gt0"] <= 2e-2), (sc["name"], sd)
+            ref = S.run_oracle(sc, "cpu", cache)
+            st = S.diff_stats(fused, ref)
+            if bits == 8:
+                pow_used = any(o[0] == "push" and o[1].get("levels_gamma", 1.0) != 1.0 for o in sc["ops"])
+                if pow_used and st["max"] > 0:
+                    # v_log / v_exp here, libm powf there: every differing sample must be one where the oracle itself moves
+                    # when its pow results move by a few ulps (fuzzmix_37: a gamma of 0.6 on premultiplied content, 0.2 %
+                    # of the samples one code off, five of them two), and HIP must lie between the oracle's outcomes
+                    from oracle import oracle as O
+                    lo, hi = ref.astype(np.int32), ref.astype(np.int32)
+                    try:
+                        for n in (-16, -8, -4, -2, -1, 1, 2, 4, 8, 16):
+                            O.lib().cpuref_set_pow_ulps(n)
+                            o = S.run_oracle(sc, "cpu", cache).astype(np.int32)
+                            lo, hi = np.minimum(lo, o), np.maximum(hi, o)
+                    finally:
+                        O.lib().cpuref_set_pow_ulps(0)
+                    g = fused.astype(np.int32)
+                    differs = g != ref
+                    assert not (differs & (hi == lo)).any() and ((g >= lo - 1) & (g <= hi + 1))[differs].all(), (sc["name"], st)
+                    assert st["max"] <= 2 and st["gt0"] <= 5e-3, (sc["name"], st)
+                else:
+                    assert st["max"] == 0, (sc["name"], st)
+            else:
+                st = P16.check(sc, fused, ref, cache)
+                assert st["max_outside_amplifying"] <= P16.LIMIT, (sc["name"], st)
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [8, 16])
 def test_fused_blend_layers_equal_the_three_draws(bits):
     """A blend-mode layer with one item is ONE op in launches of the general kernel (cghip_plan.cpp: fuse_layers): the
     item's colour goes through the UNORM store the layer texture would have given it and then through the composite.

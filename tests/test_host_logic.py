@@ -187,7 +187,13 @@ def test_surface_temporaries_follow_the_reference_renderer():
     # MIX: two additive draws into a 4-channel temporary, flushed onto the target with a surface draw (:150,:184-195)
     sc = [s for s in S.small_scenes() if s["name"] == "mix_transition"][0]
     draws, surfaces, ops, full = product_plan(sc)
-    assert surfaces == [4, 4] and full
+    assert surfaces == [4, 4] and not full  # the planner fuses the pair into one step of the lean kernel (fuse_mix_pairs)
+    assert [o.blend_body for o in ops if o.kind == K.KOP_DRAW_PLANES][-2:] == [7, 2] and not any(o.kind == K.KOP_CLEAR for o in ops)
+    A.lib().cghip_debug_no_mix_fusion(1)
+    try:
+        assert product_plan(sc)[3]  # as the reference draws it: a frame with a temporary
+    finally:
+        A.lib().cghip_debug_no_mix_fusion(0)
     assert [d.keyer for d in draws[1:3]] == [1, 1] and draws[3].source_surface == 1 and draws[3].target == 0
     # non-normal blend layer: items -> layer temporary, then composited with the layer's mode (:127-139)
     sc = [s for s in S.blend_mode_scenes() if s["name"] == "blend_screen"][0]
@@ -334,7 +340,8 @@ def check_segments(ops, segs, W, H):
                 else:
                     assert mem[s] is not None, (si, s, "loads a surface nobody stored")
                     regs[s] = mem[s]
-        for o in ops[sg["first"]:sg["first"] + sg["count"]]:
+        seg_ops = ops[sg["first"]:sg["first"] + sg["count"]]
+        for oi, o in enumerate(seg_ops):
             if o.kind == K.KOP_CLEAR:
                 regs[o.dst] = true[o.dst] = ZERO
                 continue
@@ -346,7 +353,14 @@ def check_segments(ops, segs, W, H):
                 assert regs[o.dst] == true[o.dst], (si, o.dst, "a parked key texture came back with another value")
                 continue
             if not sg["full"]:
-                assert o.dst not in (1, 2) and o.kind != K.KOP_DRAW_SURFACE
+                # without temporaries the only composite of a texture is the third op of a fused MIX pair (BB_MIX_HEAD
+                # = 7 two ops earlier, in the same launch): the step keeps the mix texture in its own registers
+                mix_tail = (o.kind == K.KOP_DRAW_SURFACE and oi >= 2 and seg_ops[oi - 2].kind == K.KOP_DRAW_PLANES and
+                            seg_ops[oi - 2].blend_body == 7 and seg_ops[oi - 1].kind == K.KOP_DRAW_PLANES and
+                            o.src_surface == 0 and sg["fast"])
+                assert o.dst not in (1, 2) and (o.kind != K.KOP_DRAW_SURFACE or mix_tail)
+            if o.kind == K.KOP_DRAW_PLANES and o.blend_body == 7 and sg["fast"]:
+                assert oi + 2 < len(seg_ops) and seg_ops[oi + 2].kind == K.KOP_DRAW_SURFACE, "a MIX pair's step cut apart"
             if sg["fast"]:
                 assert o.fast_class != 0
             if boxed:
@@ -446,9 +460,17 @@ def test_blend_mode_layers_with_one_item_are_fused_in_general_launches():
         assert len(ops3) == 20 and segs3[0]["full"] and not any(o.fused for o in ops3)
     finally:
         A.lib().cghip_debug_no_layer_fusion(0)
-    # a MIX pair shares its texture between two items: not fused
+    # a MIX pair shares its texture between two items: not this fusion; the pair has one of its own (fuse_mix_pairs),
+    # after which config 4 needs no temporary either
     ops4, segs4 = plan_with_segments(S.config4())
-    assert not any(o.fused for o in ops4) and segs4[0]["fast"] and segs4[0]["full"]
+    assert not any(o.fused for o in ops4) and segs4[0]["fast"] and not segs4[0]["full"]
+    assert [o.blend_body for o in ops4] == [0, 7, 2, 0]
+    A.lib().cghip_debug_no_mix_fusion(1)
+    try:
+        ops5, segs5 = plan_with_segments(S.config4())
+        assert len(ops5) == 5 and segs5[0]["fast"] and segs5[0]["full"]
+    finally:
+        A.lib().cghip_debug_no_mix_fusion(0)
     # unit-scale items in blend-mode layers: fused ops of the 4-pixels-per-lane kernel WITHOUT the temporaries
     sc = S.scene("blend_stack", 256, 64, [S.layer(S.bgra(256, 64, "premul", 70 + i), opacity=0.8, blend_mode=m)
                                           for i, m in enumerate(["normal", "screen", "multiply", "overlay"])])
@@ -523,6 +545,38 @@ def test_random_nested_key_scenes_replay_correctly():
     finally:
         L.cghip_debug_keep_pseudo_ops(0)
     assert parked > 100, parked
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_mix_pairs_are_fused_when_the_frame_needs_no_other_temporary(bits):
+    """fuzz_mix_scene: unit-scale stacks with MIX transitions. The planner fuses a pair (BB_MIX_HEAD = 7 on the first
+    item, the second item and the composite right behind it, no CLEAR, no temporary) when both items cover one box and
+    the frame needs no temporary otherwise - all pairs of a frame or none. The GPU test over these scenes only means
+    something if most of them take that path."""
+    from fuzz_scenes import fuzz_mix_scene
+    pairs = heads = still_full = 0
+    for seed in range(150):
+        sc = fuzz_mix_scene(seed, bits)
+        ops, segs = plan_with_segments(sc)
+        n_heads = sum(1 for o in ops if o.kind == K.KOP_DRAW_PLANES and o.blend_body == 7)
+        n_pairs = sum(1 for o in sc["ops"] if o[0] == "push" and o[1].get("is_mix")) // 2
+        full = any(s["full"] for s in segs)
+        if not (len(segs) == 1 and segs[0]["fast"]):  # a draw outside the aligned class: the frame keeps its temporaries
+            assert n_heads == 0
+            check_segments(ops, segs, sc["width"], sc["height"])
+            continue
+        # all pairs of a frame or none (a pair that draws nothing - cropped away, hidden - is no op at all)
+        assert n_heads <= n_pairs and not (full and n_heads), (seed, n_heads, n_pairs, full)
+        if n_heads:
+            assert not full and not any(o.kind == K.KOP_CLEAR and o.dst in (1, 2) for o in ops)
+        for i, o in enumerate(ops):
+            if o.kind == K.KOP_DRAW_PLANES and o.blend_body == 7:
+                b, s_ = ops[i + 1], ops[i + 2]
+                assert b.kind == K.KOP_DRAW_PLANES and s_.kind == K.KOP_DRAW_SURFACE and s_.blend_mode == 0
+                assert (o.x0, o.y0, o.x1, o.y1) == (b.x0, b.y0, b.x1, b.y1) and o.dst == b.dst == s_.dst == 0
+        check_segments(ops, segs, sc["width"], sc["height"])
+        pairs, heads, still_full = pairs + n_pairs, heads + n_heads, still_full + full
+    assert pairs > 150 and heads > 0.6 * pairs, (pairs, heads, still_full)
 
 
 def test_empty_scene_is_one_launch_that_stores_the_frame():
