@@ -2,7 +2,7 @@
 through tests/parity16.py's check WITHOUT slack (no unexplained pixels, maximum 2 LSB16 outside the amplifying pixels),
 without stopping at the first failure. Every pixel that escapes is listed with both values, the draw count and the
 tier the probes reached, into gpurun_out/parity16_hunt.json - the evidence VERDICT round 2 (next 1) asks for.
-    python tests/gpu_parity16_hunt.py [families] [n] [first_seed]   families: comma list of general,fast,fastfull,box,boxfull"""
+    python tests/gpu_parity16_hunt.py [families] [n] [first_seed]   families: comma list of general,fast,fastfull,box,boxfull,mix"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -10,11 +10,12 @@ import numpy as np
 import parity16 as P16
 import scenes as S
 import server_amd as A
-from fuzz_scenes import fuzz_scene, fuzz_fast_scene, fuzz_box_scene
+from fuzz_scenes import fuzz_scene, fuzz_fast_scene, fuzz_box_scene, fuzz_mix_scene
 
 FAMILIES = {"general": (lambda s: fuzz_scene(s, 16), 800), "fast": (lambda s: fuzz_fast_scene(s, 16, False), 300),
             "fastfull": (lambda s: fuzz_fast_scene(s, 16, True), 300), "box": (lambda s: fuzz_box_scene(s, 16, False), 300),
-            "boxfull": (lambda s: fuzz_box_scene(s, 16, True), 300)}
+            "boxfull": (lambda s: fuzz_box_scene(s, 16, True), 300),
+            "mix": (lambda s: fuzz_mix_scene(s, 16), 300)}  # fused MIX pairs (cghip_composite_fast_p<16>)
 want = (sys.argv[1] if len(sys.argv) > 1 else "general,fast,fastfull,box,boxfull").split(",")
 limit_n = int(sys.argv[2]) if len(sys.argv) > 2 else None
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
@@ -26,6 +27,8 @@ for fam in want:
     n = limit_n if limit_n else n
     escapes, worst_outside, beyond, tiers = [], 0, 0, {}
     for seed in range(first, first + n):
+        if (seed - first) % 500 == 499:
+            print("  %s seed %d  (%.0f s)" % (fam, seed, time.time() - t0), flush=True)
         sc = make(seed)
         cache = {}
         got = S.run_product(sc, mixer=m, planes_cache=cache)
