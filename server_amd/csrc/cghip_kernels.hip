@@ -2454,7 +2454,29 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
                     case BB_RGBA_ONE_KEY: fore4<1>(hs, T, K0, K1, fo); break;
                     default: fore4<2>(hs, T, K0, K1, fo); break;
                 }
-                store_rgba4<BITS>(fo, S);
+                if constexpr (FULL) { /* inside a blend-mode layer the composite's target is the layer texture (two ifs: see below) */
+                    if (hs.dst != KS_RGBA0)
+                        store_rgba4<BITS>(fo, S1);
+                    if (opaque_s(hs.dst) == KS_RGBA0)
+                        store_rgba4<BITS>(fo, S);
+                } else if constexpr (FUSED) {
+                    /* the pair is all its blend-mode layer holds (KOp::fused on the composite): over the cleared layer
+                       texture the composite leaves its fore colour through the UNORM store, and that texel goes through
+                       the layer's blend mode onto the frame, like a fused single item (BB_FUSED below) */
+                    const int lf = ops_.fused;
+                    if (lf) {
+                        f4 tex[P];
+                        static_for<0, P>([&](auto I) {
+                            constexpr int i = decltype(I)::value;
+                            tex[i] = f4{quantize<BITS>(fo.f[i].x), quantize<BITS>(fo.f[i].y), quantize<BITS>(fo.f[i].z), quantize<BITS>(fo.f[i].w)};
+                        });
+                        shade_blend_mode4<BITS>(BlendArgs{ops_.b_flags, ops_.b_local_key, ops_.b_layer_key, ops_.b_opacity, ops_.b_blend_mode}, tex, S, K0, K1);
+                    }
+                    if (!opaque_s(lf))
+                        store_rgba4<BITS>(fo, S);
+                } else {
+                    store_rgba4<BITS>(fo, S);
+                }
                 continue;
             }
         }
@@ -2778,6 +2800,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MIX_WAVES))
  * set-up per op. The instances below are the formats the BASELINE configs and live inputs use; anything else runs the
  * kernel with all bodies, as before. Same arithmetic, same code: the body is a template argument. */
 #ifndef MONO_WAVES
+/* The same step in the kernel with ONE temporary: a MIX pair inside a blend-mode layer, whose composite goes into the
+ * layer texture (cghip_plan.cpp: fuse_mix_pairs leaves at most one temporary and calls it RGBA1). */
+/* ... and in the kernel without temporaries that knows the blend modes: a MIX pair that is all its blend-mode layer
+ * holds, handed to the layer's blend in registers (KOp::fused on the pair's composite). */
+#ifndef XMIX_WAVES
+#define XMIX_WAVES 4 /* mix_blend probe, 16 layers at 2160p: 0.80 / 0.77 ms (8- / 16-bit) against 0.97 / 0.81 at 5 waves, where 17 - 26 registers spill */
+#endif
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XMIX_WAVES))) void cghip_composite_fast_xp(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, false, 2, false, -1, false, true>(ops, nops, out, W, H, field_mode, sp);
+}
+
+#ifndef ONE_MIX_WAVES
+#define ONE_MIX_WAVES 4
+#endif
+template <int BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ONE_MIX_WAVES))) void cghip_composite_fast_one_p(
+    const KOp* __restrict__ ops, int nops, void* out, int W, int H, int field_mode, KSpill sp)
+{
+    composite_fast_body<BITS, true, 0, true, -1, false, true>(ops, nops, out, W, H, field_mode, sp);
+}
+
 #define MONO_WAVES LEAN_WAVES
 #endif
 template <int BITS, int MONO>
@@ -2912,10 +2958,15 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
         const bool sampled = fast >= 2; /* the launch holds a draw with a sampled fetch body (2) or a fused layer (3) */
 #define LAUNCH_MONO(body)                                                                                              \
     hipLaunchKernelGGL((cghip_composite_fast_m<FB, body>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s)
-        if (s.mix_pairs) { /* planned only for launches of aligned draws without temporaries */
-            if (full || sampled)
+        if (s.mix_pairs) { /* planned only for launches of aligned draws with at most one temporary */
+            if (fast == 2 || (full && (!s.one_temp || sampled)))
                 return hipErrorInvalidValue;
-            hipLaunchKernelGGL((cghip_composite_fast_p<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            if (full)
+                hipLaunchKernelGGL((cghip_composite_fast_one_p<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            else if (fast == 3) /* a pair fused with its blend-mode layer */
+                hipLaunchKernelGGL((cghip_composite_fast_xp<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
+            else
+                hipLaunchKernelGGL((cghip_composite_fast_p<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
             return hipGetLastError();
         }
         const int mono = (!full && !sampled && !cghip_g_no_mono) ? s.mono : -1;

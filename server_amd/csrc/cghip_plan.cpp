@@ -859,6 +859,8 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
             const KOp& o = ops[(size_t)i];
             if (o.kind == KOP_DRAW_PLANES)
                 sg.ext = std::max(sg.ext, o.fused ? 2 : (o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END) ? 1 : 0);
+            if (o.kind == KOP_DRAW_SURFACE && o.fused) /* the composite of a MIX pair that is all its blend-mode layer holds */
+                sg.ext = 2;
         }
         sg.mix_pairs = false;
         for (int i = sg.first; i < sg.first + sg.count; ++i)
@@ -1065,13 +1067,14 @@ static void fuse_mix_pairs(const cghip_format& fmt, frame_plan* out)
         return;
     const std::vector<KOp>& ops = out->ops;
     const int               n   = (int)ops.size();
-    for (const KOp& o : ops) /* the step exists in the lean kernel of aligned draws only (cghip_composite_fast_p) */
+    for (const KOp& o : ops) /* the step exists in the kernels of aligned draws only (cghip_composite_fast_p, _one_p) */
         if (!is_marker(o) && (o.fused || (o.kind == KOP_DRAW_PLANES && o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END)))
             return;
-    std::vector<int>        head; /* index of the CLEAR of every pair that qualifies */
-    std::vector<char>       in_pair((size_t)n, 0);
+    const uint32_t          TEMPS = surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2);
+    std::vector<int>        head;   /* index of the CLEAR of every pair that qualifies */
+    std::vector<char>       in_pair((size_t)n, 0), has_clear((size_t)n, 0);
     for (int c = 0; c + 3 < n; ++c) {
-        const KOp &C = ops[(size_t)c], &A = ops[(size_t)c + 1], &B = ops[(size_t)c + 2], &S = ops[(size_t)c + 3];
+        const KOp &C = ops[(size_t)c], &A = ops[(size_t)c + 1], &B = ops[(size_t)c + 2];
         if (C.kind != KOP_CLEAR || (C.dst != KS_RGBA1 && C.dst != KS_RGBA2))
             continue;
         const int T = C.dst;
@@ -1082,13 +1085,20 @@ static void fuse_mix_pairs(const cghip_format& fmt, frame_plan* out)
         };
         if (!item(A) || !item(B) || A.x0 != B.x0 || A.y0 != B.y0 || A.x1 != B.x1 || A.y1 != B.y1)
             continue;
-        if (S.kind != KOP_DRAW_SURFACE || S.src_surface != T || S.dst != KS_RGBA0 || S.blend_mode != 0 || S.fused ||
+        /* inside a blend-mode layer the layer texture is cleared between the items and the composite (the resolver
+           creates it when the first thing is drawn into it, image_mixer.cpp:118-129): that CLEAR stays where it is */
+        const bool c2 = ops[(size_t)c + 3].kind == KOP_CLEAR && c + 4 < n;
+        const KOp& S  = ops[(size_t)c + 3 + (c2 ? 1 : 0)];
+        if (c2 && (ops[(size_t)c + 3].dst == T || ops[(size_t)c + 3].dst != S.dst))
+            continue;
+        if (S.kind != KOP_DRAW_SURFACE || S.src_surface != T || S.dst == T || S.dst > KS_RGBA2 || S.blend_mode != 0 || S.fused ||
             S.fast_class != FC_SURFACE || (S.flags & (KF_LEVELS | KF_CSB | KF_CHROMA | KF_INVERT)))
             continue;
         if (S.x0 != (A.x0 & ~3) || S.x1 != std::min(fmt.width, (A.x1 + 3) & ~3) || S.y0 != A.y0 || S.y1 != A.y1)
             continue; /* the composite's lanes are the items' lanes */
-        bool dead = true; /* nothing looks at T afterwards before it is cleared again */
-        for (int k = c + 4; k < n && dead; ++k) {
+        const int last = c + 3 + (c2 ? 1 : 0);
+        bool      dead = true; /* nothing looks at T afterwards before it is cleared again */
+        for (int k = last + 1; k < n && dead; ++k) {
             const KOp& o = ops[(size_t)k];
             if (o.kind == KOP_CLEAR && o.dst == T)
                 break;
@@ -1097,32 +1107,108 @@ static void fuse_mix_pairs(const cghip_format& fmt, frame_plan* out)
         if (!dead)
             continue;
         head.push_back(c);
-        in_pair[(size_t)c] = in_pair[(size_t)c + 1] = in_pair[(size_t)c + 2] = in_pair[(size_t)c + 3] = 1;
-        c += 3;
+        has_clear[(size_t)c] = c2;
+        in_pair[(size_t)c] = in_pair[(size_t)c + 1] = in_pair[(size_t)c + 2] = in_pair[(size_t)last] = 1;
+        c = last;
     }
     if (head.empty())
         return;
-    for (int i = 0; i < n; ++i) /* all or nothing: a temporary left anywhere keeps the frame in the kernels that hold one */
-        if (!in_pair[(size_t)i] && (refs_of(ops[(size_t)i]) & (surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2))))
-            return;
+    /* A pair that is all its blend-mode layer holds - CLEAR L; the pair -> L; L -> frame with the layer's mode, L dead
+       afterwards - can hand its result to the mode's blend in registers as well (KOp::fused on the pair's composite,
+       which takes the layer composite's b_* fields like a fused single item, fuse_layers): over the cleared L the
+       composite's result is its fore colour through the UNORM store. Then the frame needs no temporary at all. Taken
+       only if that holds for every pair composited into a temporary and nothing else uses one: the blend call exists in
+       the step of the kernel without temporaries (cghip_composite_fast_xp), not of the one that holds the layer. */
+    std::vector<char> layer_fused((size_t)n, 0), gone((size_t)n, 0);
+    bool              all_layers = !g_no_layer_fusion;
+    for (int c : head) {
+        const int  s_at = c + 3 + (has_clear[(size_t)c] ? 1 : 0);
+        const KOp& S    = ops[(size_t)s_at];
+        if (S.dst == KS_RGBA0)
+            continue;
+        bool ok = has_clear[(size_t)c] && s_at + 1 < n;
+        if (ok) {
+            const KOp& M = ops[(size_t)s_at + 1];
+            ok = M.kind == KOP_DRAW_SURFACE && M.src_surface == S.dst && M.dst == KS_RGBA0 && M.blend_mode != 0 && !M.fused &&
+                 M.fast_class == FC_SURFACE && !(M.flags & (KF_LEVELS | KF_CSB | KF_CHROMA)) && M.x0 == S.x0 && M.x1 == S.x1 &&
+                 M.y0 == S.y0 && M.y1 == S.y1;
+            for (int k = s_at + 2; k < n && ok; ++k) { /* nothing looks at L afterwards before it is cleared again */
+                const KOp& o = ops[(size_t)k];
+                if (o.kind == KOP_CLEAR && o.dst == S.dst)
+                    break;
+                ok = !(refs_of(o) & surf_bit(S.dst));
+            }
+        }
+        if (!ok) {
+            all_layers = false;
+            break;
+        }
+        layer_fused[(size_t)c] = 1;
+        gone[(size_t)c + 3] = gone[(size_t)s_at + 1] = 1; /* L's CLEAR and the layer's composite */
+    }
+    if (all_layers)
+        for (int i = 0; i < n && all_layers; ++i)
+            if (!in_pair[(size_t)i] && !gone[(size_t)i] && (refs_of(ops[(size_t)i]) & TEMPS))
+                all_layers = false;
+    if (!all_layers) {
+        std::fill(layer_fused.begin(), layer_fused.end(), 0);
+        std::fill(gone.begin(), gone.end(), 0);
+    }
+    /* All or nothing, and at most ONE temporary left: the step exists in the kernel without temporaries and in the one
+       that holds a single temporary (KSpill::one_temp), not in the one with two at its 128-register bound. What is left
+       are the targets of the pairs' composites and whatever the other ops use. */
+    uint32_t left = 0;
+    for (int i = 0; i < n; ++i)
+        if (!in_pair[(size_t)i] && !gone[(size_t)i])
+            left |= refs_of(ops[(size_t)i]) & TEMPS;
+    for (int c : head)
+        if (!layer_fused[(size_t)c])
+            left |= surf_bit(ops[(size_t)c + 3 + (has_clear[(size_t)c] ? 1 : 0)].dst) & TEMPS;
+    if (left == TEMPS)
+        return;
+    auto rename = [&](int32_t& surf) { /* the one temporary left is RGBA1 to the kernel */
+        if (left == surf_bit(KS_RGBA2) && surf == KS_RGBA2)
+            surf = KS_RGBA1;
+    };
     std::vector<KOp> fused;
     fused.reserve((size_t)n);
     size_t h = 0;
     for (int i = 0; i < n; ++i) {
         if (h < head.size() && i == head[h]) {
-            KOp A = ops[(size_t)i + 1], B = ops[(size_t)i + 2], S = ops[(size_t)i + 3];
+            const bool c2 = has_clear[(size_t)i] != 0;
+            KOp A = ops[(size_t)i + 1], B = ops[(size_t)i + 2], S = ops[(size_t)i + 3 + (c2 ? 1 : 0)];
+            if (layer_fused[(size_t)i]) {
+                const KOp& M = ops[(size_t)i + 5];
+                S.fused = 1;
+                S.ax0 = S.x0, S.ay0 = S.y0, S.ax1 = S.x1, S.ay1 = S.y1;
+                S.dst = M.dst;
+                S.b_blend_mode = M.blend_mode, S.b_local_key = M.local_key, S.b_layer_key = M.layer_key;
+                S.b_flags = M.flags, S.b_opacity = M.opacity;
+                ++i; /* M */
+            } else if (c2) {
+                KOp C2 = ops[(size_t)i + 3];
+                rename(C2.dst);
+                fused.push_back(C2);
+            }
+            rename(S.dst);
             A.blend_body = BB_MIX_HEAD;
-            A.dst = B.dst = KS_RGBA0; /* what the step as a whole writes */
-            S.src_surface = KS_RGBA0; /* never read as a source: the step hands the texture over in registers */
+            A.dst = B.dst = S.dst;   /* what the step as a whole writes */
+            S.src_surface = S.dst;   /* never read as a source: the step hands the texture over in registers */
             fused.push_back(A), fused.push_back(B), fused.push_back(S);
-            i += 3;
+            i += 3 + (c2 ? 1 : 0);
             ++h;
             continue;
         }
-        fused.push_back(ops[(size_t)i]);
+        KOp o = ops[(size_t)i];
+        if (!is_pseudo(o)) {
+            rename(o.dst);
+            if (o.kind == KOP_DRAW_SURFACE)
+                rename(o.src_surface);
+        }
+        fused.push_back(o);
     }
     out->ops.swap(fused);
-    out->full = false;
+    out->full = left != 0;
     out->mix_pairs = true;
 }
 

@@ -177,13 +177,16 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))
 
 
-def fuzz_mix_scene(seed, bits=8):
+def fuzz_mix_scene(seed, bits=8, blend=False):
     """Unit-scale stacks without blend-mode layers in which about every second fill layer is a MIX transition (two is_mix
     items in one layer, image_mixer.cpp:187-225): what the planner fuses into one step of the lean kernel
     (cghip_plan.cpp: fuse_mix_pairs). The stack is fuzz_fast_scene's (keys, every adjustment, crops, clips, field modes);
-    the second item of a pair is another source of the frame's size, sometimes with adjustments of its own."""
+    the second item of a pair is another source of the frame's size, sometimes with adjustments of its own.
+    blend: about every second of those layers has a blend mode, i.e. the pair is composited into the layer's texture and
+    that onto the frame (image_mixer.cpp:118-129): the step in the kernel with one temporary (cghip_composite_fast_one_p)."""
     base = fuzz_fast_scene(seed, bits, False)
     rng = random.Random(6000011 * seed + bits + 3)
+    modes = random.Random(7000003 * seed + bits + 5)  # a stream of its own: the scenes without blend modes stay as they are
     W, H = base["width"], base["height"]
     ops = []
     flat = base["ops"]  # scene() flattened the layers: without blend-mode layers and MIX pairs they are push / visit / pop triples
@@ -217,11 +220,13 @@ def fuzz_mix_scene(seed, bits=8):
                       levels_max_output=1.0)
         if rng.random() < 0.15:
             ot.update(brightness=1.1, saturation=0.8, contrast=1.2)
+        if blend and modes.random() < 0.5:
+            lt["blend_mode"] = modes.choice(["screen", "multiply", "overlay", "add", "difference", "lighten", "hard_light", "color"])
         ops.append([("push", lt),
                     ("push", dict(it, is_mix=1, opacity=round(1.0 - d, 2))), ("visit", lay[1][1]), ("pop",),
                     ("push", dict(ot, is_mix=1, opacity=d)), ("visit", other), ("pop",),
                     ("pop",)])
-    return S.scene("fuzzmix_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=base["field_mode"])
+    return S.scene("fuzzmix%s_%d_%dbit" % ("b" if blend else "", seed, bits), W, H, ops, bits=bits, field_mode=base["field_mode"])
 
 
 def fuzz_box_scene(seed, bits=8, full=False, mirror=False):

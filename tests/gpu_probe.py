@@ -43,6 +43,10 @@ def stack(kind, bits):
 which = os.environ.get("PROBE", "plain,key,chroma,levels,bgra").split(",")
 if os.environ.get("PROBE_NO_MONO") and hasattr(A.lib(), "cghip_debug_no_mono_kernels"):  # one-format stacks in the kernel with all fetch bodies (A/B of cghip_composite_fast_m)
     A.lib().cghip_debug_no_mono_kernels(1)
+if os.environ.get("PROBE_NO_MIX_FUSION"):  # MIX pairs as four draws (A/B of cghip_composite_fast_p / _one_p)
+    A.lib().cghip_debug_no_mix_fusion(1)
+if os.environ.get("PROBE_NO_LAYER_FUSION"):
+    A.lib().cghip_debug_no_layer_fusion(1)
 if os.environ.get("PROBE_FORCE_GENERAL"):
     A.lib().cghip_debug_force_general_kernel(1)
 BLEND = os.environ.get("PROBE_BLEND", "screen")

@@ -368,7 +368,10 @@ def check_segments(ops, segs, W, H):
             reads = [o.dst, o.local_key, o.layer_key] + ([o.src_surface] if o.kind == K.KOP_DRAW_SURFACE else [])
             if o.fused:  # a blend-mode layer with one item as ONE op: the composite's keys are read too
                 reads += [o.b_local_key, o.b_layer_key]
-                assert o.kind == K.KOP_DRAW_PLANES and (not sg["fast"] or o.blend_body == 6)  # BB_FUSED
+                if o.kind == K.KOP_DRAW_SURFACE:  # the composite of a MIX pair that is all its blend-mode layer holds
+                    assert sg["fast"] and not sg["full"] and oi >= 2 and seg_ops[oi - 2].blend_body == 7 and o.dst == 0
+                else:
+                    assert o.kind == K.KOP_DRAW_PLANES and (not sg["fast"] or o.blend_body == 6)  # BB_FUSED
                 assert o.x0 <= o.ax0 and o.ax1 <= o.x1 and o.y0 <= o.ay0 and o.ay1 <= o.y1
             for s in reads:
                 if s >= 0:
@@ -547,16 +550,20 @@ def test_random_nested_key_scenes_replay_correctly():
     assert parked > 100, parked
 
 
+@pytest.mark.parametrize("blend", [False, True])
 @pytest.mark.parametrize("bits", [8, 16])
-def test_mix_pairs_are_fused_when_the_frame_needs_no_other_temporary(bits):
-    """fuzz_mix_scene: unit-scale stacks with MIX transitions. The planner fuses a pair (BB_MIX_HEAD = 7 on the first
-    item, the second item and the composite right behind it, no CLEAR, no temporary) when both items cover one box and
-    the frame needs no temporary otherwise - all pairs of a frame or none. The GPU test over these scenes only means
-    something if most of them take that path."""
+def test_mix_pairs_are_fused_when_the_frame_needs_at_most_one_other_temporary(bits, blend):
+    """fuzz_mix_scene: unit-scale stacks with MIX transitions, with blend=True about half of them inside blend-mode
+    layers. The planner fuses a pair (BB_MIX_HEAD = 7 on the first item, the second item and the composite right behind
+    it, the mix texture's CLEAR gone) when both items cover one box - all qualifying pairs of a frame, provided the frame
+    is then left with at most ONE temporary (the layer texture a pair is composited into, or the mix texture of a pair
+    that does not qualify), which the planner calls RGBA1. A pair that is all its blend-mode layer holds is fused with
+    the layer's composite as well (`fused` on the pair's composite) when the frame then needs no temporary at all. The
+    GPU test over these scenes only means something if most of them take these paths."""
     from fuzz_scenes import fuzz_mix_scene
-    pairs = heads = still_full = 0
+    pairs = heads = still_full = into_layer = layer_fused = 0
     for seed in range(150):
-        sc = fuzz_mix_scene(seed, bits)
+        sc = fuzz_mix_scene(seed, bits, blend)
         ops, segs = plan_with_segments(sc)
         n_heads = sum(1 for o in ops if o.kind == K.KOP_DRAW_PLANES and o.blend_body == 7)
         n_pairs = sum(1 for o in sc["ops"] if o[0] == "push" and o[1].get("is_mix")) // 2
@@ -565,18 +572,24 @@ def test_mix_pairs_are_fused_when_the_frame_needs_no_other_temporary(bits):
             assert n_heads == 0
             check_segments(ops, segs, sc["width"], sc["height"])
             continue
-        # all pairs of a frame or none (a pair that draws nothing - cropped away, hidden - is no op at all)
-        assert n_heads <= n_pairs and not (full and n_heads), (seed, n_heads, n_pairs, full)
-        if n_heads:
-            assert not full and not any(o.kind == K.KOP_CLEAR and o.dst in (1, 2) for o in ops)
+        assert n_heads <= n_pairs  # a pair that draws nothing - cropped away, hidden - is no op at all
+        if n_heads:  # nothing touches the second temporary any more
+            for o in ops:
+                assert o.dst != 2 and not (o.kind == K.KOP_DRAW_SURFACE and o.src_surface == 2), (seed, o.kind, o.dst)
+        if not blend and n_heads and not full:
+            assert not any(o.kind == K.KOP_CLEAR and o.dst in (1, 2) for o in ops)
         for i, o in enumerate(ops):
             if o.kind == K.KOP_DRAW_PLANES and o.blend_body == 7:
                 b, s_ = ops[i + 1], ops[i + 2]
                 assert b.kind == K.KOP_DRAW_PLANES and s_.kind == K.KOP_DRAW_SURFACE and s_.blend_mode == 0
-                assert (o.x0, o.y0, o.x1, o.y1) == (b.x0, b.y0, b.x1, b.y1) and o.dst == b.dst == s_.dst == 0
+                assert (o.x0, o.y0, o.x1, o.y1) == (b.x0, b.y0, b.x1, b.y1) and o.dst == b.dst == s_.dst and o.dst in (0, 1)
+                into_layer += o.dst == 1
+                layer_fused += bool(s_.fused)
+                assert not s_.fused or (not full and s_.dst == 0 and s_.b_blend_mode != 0)
         check_segments(ops, segs, sc["width"], sc["height"])
         pairs, heads, still_full = pairs + n_pairs, heads + n_heads, still_full + full
     assert pairs > 150 and heads > 0.6 * pairs, (pairs, heads, still_full)
+    assert (into_layer + layer_fused > 0.2 * heads and layer_fused > 0.05 * heads) if blend else into_layer == layer_fused == 0, (into_layer, layer_fused, heads)
 
 
 def test_empty_scene_is_one_launch_that_stores_the_frame():
