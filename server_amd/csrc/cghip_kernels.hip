@@ -2959,11 +2959,11 @@ extern "C" hipError_t LAUNCH_NAME(const KOp* d_ops, int nops, void* d_out, int W
 #define LAUNCH_MONO(body)                                                                                              \
     hipLaunchKernelGGL((cghip_composite_fast_m<FB, body>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s)
         if (s.mix_pairs) { /* planned only for launches of aligned draws with at most one temporary */
-            if (fast == 2 || (full && (!s.one_temp || sampled)))
+            if (full && (!s.one_temp || sampled))
                 return hipErrorInvalidValue;
             if (full)
                 hipLaunchKernelGGL((cghip_composite_fast_one_p<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
-            else if (fast == 3) /* a pair fused with its blend-mode layer */
+            else if (sampled) /* a pair fused with its blend-mode layer, or sampled boxes / fused layers elsewhere in the frame */
                 hipLaunchKernelGGL((cghip_composite_fast_xp<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);
             else
                 hipLaunchKernelGGL((cghip_composite_fast_p<FB>), grid, block, (size_t)cghip_g_pad_lds, stream, d_ops, nops, d_out, W, H, field_mode, s);

@@ -1067,9 +1067,10 @@ static void fuse_mix_pairs(const cghip_format& fmt, frame_plan* out)
         return;
     const std::vector<KOp>& ops = out->ops;
     const int               n   = (int)ops.size();
-    for (const KOp& o : ops) /* the step exists in the kernels of aligned draws only (cghip_composite_fast_p, _one_p) */
-        if (!is_marker(o) && (o.fused || (o.kind == KOP_DRAW_PLANES && o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END)))
-            return;
+    bool has_ext = false; /* sampled boxes or fused single-item layers elsewhere in the frame: the step then exists in the
+                             kernel without temporaries only (cghip_composite_fast_xp has every body), see below */
+    for (const KOp& o : ops)
+        has_ext = has_ext || (!is_marker(o) && (o.fused || (o.kind == KOP_DRAW_PLANES && o.fetch_body >= FB_RECT8 && o.fetch_body < FB_SAMPLED_END)));
     const uint32_t          TEMPS = surf_bit(KS_RGBA1) | surf_bit(KS_RGBA2);
     std::vector<int>        head;   /* index of the CLEAR of every pair that qualifies */
     std::vector<char>       in_pair((size_t)n, 0), has_clear((size_t)n, 0);
@@ -1164,7 +1165,7 @@ static void fuse_mix_pairs(const cghip_format& fmt, frame_plan* out)
     for (int c : head)
         if (!layer_fused[(size_t)c])
             left |= surf_bit(ops[(size_t)c + 3 + (has_clear[(size_t)c] ? 1 : 0)].dst) & TEMPS;
-    if (left == TEMPS)
+    if (left == TEMPS || (left != 0 && has_ext))
         return;
     auto rename = [&](int32_t& surf) { /* the one temporary left is RGBA1 to the kernel */
         if (left == surf_bit(KS_RGBA2) && surf == KS_RGBA2)

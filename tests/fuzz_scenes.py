@@ -177,14 +177,16 @@ def fuzz_fast_scene(seed, bits=8, full=False):
     return S.scene("fuzzfast_%d_%dbit" % (seed, bits), W, H, ops, bits=bits, field_mode=rng.choice([0, 0, 1, 2]))
 
 
-def fuzz_mix_scene(seed, bits=8, blend=False):
+def fuzz_mix_scene(seed, bits=8, blend=False, boxes=False):
     """Unit-scale stacks without blend-mode layers in which about every second fill layer is a MIX transition (two is_mix
     items in one layer, image_mixer.cpp:187-225): what the planner fuses into one step of the lean kernel
     (cghip_plan.cpp: fuse_mix_pairs). The stack is fuzz_fast_scene's (keys, every adjustment, crops, clips, field modes);
     the second item of a pair is another source of the frame's size, sometimes with adjustments of its own.
     blend: about every second of those layers has a blend mode, i.e. the pair is composited into the layer's texture and
-    that onto the frame (image_mixer.cpp:118-129): the step in the kernel with one temporary (cghip_composite_fast_one_p)."""
-    base = fuzz_fast_scene(seed, bits, False)
+    that onto the frame (image_mixer.cpp:118-129): the step in the kernel with one temporary (cghip_composite_fast_one_p).
+    boxes: the stack is fuzz_box_scene's - picture-in-picture boxes between the unit-scale layers, and only the latter
+    become MIX pairs: frames whose other draws need the sampled bodies (cghip_composite_fast_xp)."""
+    base = fuzz_box_scene(seed, bits, False) if boxes else fuzz_fast_scene(seed, bits, False)
     rng = random.Random(6000011 * seed + bits + 3)
     modes = random.Random(7000003 * seed + bits + 5)  # a stream of its own: the scenes without blend modes stay as they are
     W, H = base["width"], base["height"]
@@ -193,7 +195,7 @@ def fuzz_mix_scene(seed, bits=8, blend=False):
     assert len(flat) % 3 == 0 and all(flat[k][0] == ("push", "visit", "pop")[k % 3] for k in range(len(flat)))
     for i, lay in enumerate([flat[k:k + 3] for k in range(0, len(flat), 3)]):
         t = lay[0][1]
-        if t.get("is_key") or t.get("invert") or rng.random() < 0.5:
+        if t.get("is_key") or t.get("invert") or (boxes and ("fill_scale" in t or "fill_translation" in t)) or rng.random() < (0.2 if boxes else 0.5):
             ops.append(lay)
             continue
         d = rng.choice([0.5, 0.25, round(rng.random(), 2)])
@@ -226,7 +228,7 @@ def fuzz_mix_scene(seed, bits=8, blend=False):
                     ("push", dict(it, is_mix=1, opacity=round(1.0 - d, 2))), ("visit", lay[1][1]), ("pop",),
                     ("push", dict(ot, is_mix=1, opacity=d)), ("visit", other), ("pop",),
                     ("pop",)])
-    return S.scene("fuzzmix%s_%d_%dbit" % ("b" if blend else "", seed, bits), W, H, ops, bits=bits, field_mode=base["field_mode"])
+    return S.scene("fuzzmix%s%s_%d_%dbit" % ("b" if blend else "", "x" if boxes else "", seed, bits), W, H, ops, bits=bits, field_mode=base["field_mode"])
 
 
 def fuzz_box_scene(seed, bits=8, full=False, mirror=False):

@@ -18,7 +18,7 @@ t0 = time.time()
 for seed in range(lo, hi):
     for sc in (fuzz_box_scene(seed, 8, seed % 2 == 1), fuzz_fast_scene(seed, 8, seed % 2 == 0), fuzz_scene(seed, 8),
                fuzz_box_scene(seed, 8, seed % 2 == 0, mirror=True), fuzz_nested_scene(seed, 8), fuzz_mix_scene(seed, 8),
-               fuzz_mix_scene(seed, 8, True)):  # the last four: round 3
+               fuzz_mix_scene(seed, 8, True), fuzz_mix_scene(seed, 8, seed % 2 == 0, True)):  # the last five: round 3
         cache = {}
         got = S.run_product(sc, mixer=m, planes_cache=cache)
         L.cghip_debug_force_general_kernel(1)

@@ -2,7 +2,7 @@
 through tests/parity16.py's check WITHOUT slack (no unexplained pixels, maximum 2 LSB16 outside the amplifying pixels),
 without stopping at the first failure. Every pixel that escapes is listed with both values, the draw count and the
 tier the probes reached, into gpurun_out/parity16_hunt.json - the evidence VERDICT round 2 (next 1) asks for.
-    python tests/gpu_parity16_hunt.py [families] [n] [first_seed]   families: comma list of general,fast,fastfull,box,boxfull,mix,mixblend"""
+    python tests/gpu_parity16_hunt.py [families] [n] [first_seed]   families: comma list of general,fast,fastfull,box,boxfull,mix,mixblend,mixboxes"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,8 @@ FAMILIES = {"general": (lambda s: fuzz_scene(s, 16), 800), "fast": (lambda s: fu
             "fastfull": (lambda s: fuzz_fast_scene(s, 16, True), 300), "box": (lambda s: fuzz_box_scene(s, 16, False), 300),
             "boxfull": (lambda s: fuzz_box_scene(s, 16, True), 300),
             "mix": (lambda s: fuzz_mix_scene(s, 16), 300),  # fused MIX pairs (cghip_composite_fast_p<16>)
-            "mixblend": (lambda s: fuzz_mix_scene(s, 16, True), 300)}  # ... inside blend-mode layers (cghip_composite_fast_one_p<16>)
+            "mixblend": (lambda s: fuzz_mix_scene(s, 16, True), 300),
+            "mixboxes": (lambda s: fuzz_mix_scene(s, 16, s % 2 == 0, True), 300)}  # ... with sampled boxes in the frame (_xp)  # ... inside blend-mode layers (cghip_composite_fast_one_p<16>)
 want = (sys.argv[1] if len(sys.argv) > 1 else "general,fast,fastfull,box,boxfull").split(",")
 limit_n = int(sys.argv[2]) if len(sys.argv) > 2 else None
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0

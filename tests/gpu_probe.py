@@ -15,7 +15,7 @@ BLEND_MODE = os.environ.get("PROBE_BLEND", "screen")
 
 
 def stack(kind, bits):
-    t = {"mix_blend": {}, "uyvy": dict(opacity=0.8), "g_uyvy_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
+    t = {"mix_blend": {}, "mix_rect": {}, "uyvy": dict(opacity=0.8), "g_uyvy_rect": dict(opacity=0.8, fill_scale=[0.97, 0.97]),
          "g_uyvy_rot": dict(opacity=0.8, angle=0.05),"plain": dict(opacity=0.8), "key": dict(is_key=1), "chroma": dict(opacity=0.75, **S.CHROMA),
          "levels": dict(opacity=0.7, **S.LEVELS), "bgra": dict(opacity=0.8),
          # general-kernel paths: scaled (axis-aligned), rotated, perspective, unit-scale with a blend mode
@@ -36,6 +36,15 @@ def stack(kind, bits):
             ops.append([("push", dict(layer_depth=1, blend_mode=BLEND_MODE, opacity=0.8)),
                         ("push", dict(is_mix=1, opacity=0.6)), ("visit", spec), ("pop",),
                         ("push", dict(is_mix=1, opacity=0.4)), ("visit", other), ("pop",), ("pop",)])
+            continue
+        if kind == "mix_rect":  # MIX pairs between scaled boxes: frames that need the sampled bodies next to the step
+            if i % 2:
+                ops.append(S.layer(spec, opacity=0.8, fill_scale=[0.97, 0.97]))
+            else:
+                other = S.bgra(W, H, "premul", 700 + i, bits=bits)
+                ops.append([("push", dict(layer_depth=1, opacity=0.8)),
+                            ("push", dict(is_mix=1, opacity=0.6)), ("visit", spec), ("pop",),
+                            ("push", dict(is_mix=1, opacity=0.4)), ("visit", other), ("pop",), ("pop",)])
             continue
         ops.append(S.layer(spec, **t))
     return S.scene("%s_%d" % (kind, bits), W, H, ops, bits=bits)

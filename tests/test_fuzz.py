@@ -338,14 +338,14 @@ def test_mirrored_boxes_match_the_general_kernel_and_the_oracle(bits):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blend", [False, True])
+@pytest.mark.parametrize("blend,boxes", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("bits", [8, 16])
-def test_fused_mix_pairs_equal_the_four_draws(bits, blend):
+def test_fused_mix_pairs_equal_the_four_draws(bits, blend, boxes):
     """A MIX transition (CLEAR, two items into the mix texture, its composite) is ONE step of the 4-pixels-per-lane
     kernel when the frame is left with at most one temporary (cghip_plan.cpp: fuse_mix_pairs; cghip_composite_fast_p
     without a temporary; for pairs inside blend-mode layers - blend=True - cghip_composite_fast_xp when the pair is all
     its layer holds and goes through the layer's blend in registers, cghip_composite_fast_one_p when its composite goes
-    into the layer texture): same arithmetic in the same order as the four ops in the kernels that hold the mix
+    into the layer texture; boxes=True: sampled boxes elsewhere in the frame, cghip_composite_fast_xp again): same arithmetic in the same order as the four ops in the kernels that hold the mix
     texture. 300 random stacks each and BASELINE config 4: bit-identical in 8-bit frames (to the neighbouring code in
     16-bit frames, where two kernels contract different multiply-adds), and against the oracle as everywhere else."""
     import server_amd as A
@@ -353,7 +353,7 @@ def test_fused_mix_pairs_equal_the_four_draws(bits, blend):
     m = A.Mixer(channel_id=8, gpu=0)
     L = A.lib()
     try:
-        for sc in [fuzz_mix_scene(seed, bits, blend) for seed in range(300)] + ([S.config4()] if bits == 8 and not blend else []):
+        for sc in [fuzz_mix_scene(seed, bits, blend, boxes) for seed in range(300)] + ([S.config4()] if bits == 8 and not blend and not boxes else []):
             cache = {}
             fused = S.run_product(sc, mixer=m, planes_cache=cache)
             L.cghip_debug_no_mix_fusion(1)

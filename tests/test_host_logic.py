@@ -280,7 +280,7 @@ def test_fast_class_fuzz_scenes_are_planned_for_the_fast_kernel(full):
         _d, _s, ops, is_full = product_plan(sc)
         assert K.last_plan_fast or not ops, (seed, [(o.kind, o.fast_class) for o in ops])
         n_full += int(is_full)
-    assert (n_full > 30) if full else (n_full == 0)
+    assert (n_full > 20) if full else (n_full == 0)  # 26 since MIX pairs fuse next to fused layers (43 with cghip_debug_no_mix_fusion)
 
 
 @pytest.mark.parametrize("bits", [8, 16])
@@ -499,9 +499,18 @@ def test_nested_blend_sublayer_with_a_mix_pair_fits_two_temporaries():
                       [("push", dict(opacity=0.5)), ("visit", S.bgra(W, H, "premul", 83)), ("pop",), ("pop",)]])
     assert _draw_sequence(nested) == [("P", 0, -1), ("M", 2, -1), ("M", 2, -1), ("S", 1, 2), ("S", 0, 1), ("P", 3, -1),
                                       ("S", 0, 3)]
-    _d, surfaces, ops, full = product_plan(nested)
+    A.lib().cghip_debug_no_mix_fusion(1)  # the draws as the renderer issues them
+    try:
+        _d, surfaces, ops, full = product_plan(nested)
+    finally:
+        A.lib().cghip_debug_no_mix_fusion(0)
     assert len(surfaces) == 4 and full and {o.dst for o in ops} == {0, 1, 2}
     assert len(oracle_log(nested)) == 7
+    # what runs: the pair fused with its sublayer's composite, the item with its layer's - no temporary left at all
+    _d, surfaces, ops, full = product_plan(nested)
+    assert not full and [(o.kind, o.blend_body, o.fused) for o in ops] == [
+        (K.KOP_DRAW_PLANES, 0, 0), (K.KOP_DRAW_PLANES, 7, 0), (K.KOP_DRAW_PLANES, 2, 0), (K.KOP_DRAW_SURFACE, 0, 1),
+        (K.KOP_DRAW_PLANES, 6, 1)]
 
 
 def test_more_than_two_live_key_textures_are_parked_in_hbm_across_cuts():
@@ -550,22 +559,27 @@ def test_random_nested_key_scenes_replay_correctly():
     assert parked > 100, parked
 
 
-@pytest.mark.parametrize("blend", [False, True])
+@pytest.mark.parametrize("blend,boxes", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("bits", [8, 16])
-def test_mix_pairs_are_fused_when_the_frame_needs_at_most_one_other_temporary(bits, blend):
+def test_mix_pairs_are_fused_when_the_frame_needs_at_most_one_other_temporary(bits, blend, boxes):
     """fuzz_mix_scene: unit-scale stacks with MIX transitions, with blend=True about half of them inside blend-mode
     layers. The planner fuses a pair (BB_MIX_HEAD = 7 on the first item, the second item and the composite right behind
     it, the mix texture's CLEAR gone) when both items cover one box - all qualifying pairs of a frame, provided the frame
     is then left with at most ONE temporary (the layer texture a pair is composited into, or the mix texture of a pair
     that does not qualify), which the planner calls RGBA1. A pair that is all its blend-mode layer holds is fused with
     the layer's composite as well (`fused` on the pair's composite) when the frame then needs no temporary at all. The
-    GPU test over these scenes only means something if most of them take these paths."""
+    boxes=True: sampled boxes elsewhere in the frame, which the step tolerates when no temporary is left at all.
+    The GPU test over these scenes only means something if most of them take these paths."""
     from fuzz_scenes import fuzz_mix_scene
     pairs = heads = still_full = into_layer = layer_fused = 0
-    for seed in range(150):
-        sc = fuzz_mix_scene(seed, bits, blend)
+    sampled_too = 0
+    for seed in range(300 if boxes else 150):
+        sc = fuzz_mix_scene(seed, bits, blend, boxes)
         ops, segs = plan_with_segments(sc)
         n_heads = sum(1 for o in ops if o.kind == K.KOP_DRAW_PLANES and o.blend_body == 7)
+        if n_heads and any(o.kind == K.KOP_DRAW_PLANES and (o.fused or 12 <= o.fetch_body < 24) for o in ops):
+            sampled_too += 1
+            assert not any(s["full"] for s in segs)  # with sampled boxes or fused layers in the frame: only without a temporary
         n_pairs = sum(1 for o in sc["ops"] if o[0] == "push" and o[1].get("is_mix")) // 2
         full = any(s["full"] for s in segs)
         if not (len(segs) == 1 and segs[0]["fast"]):  # a draw outside the aligned class: the frame keeps its temporaries
@@ -588,7 +602,8 @@ def test_mix_pairs_are_fused_when_the_frame_needs_at_most_one_other_temporary(bi
                 assert not s_.fused or (not full and s_.dst == 0 and s_.b_blend_mode != 0)
         check_segments(ops, segs, sc["width"], sc["height"])
         pairs, heads, still_full = pairs + n_pairs, heads + n_heads, still_full + full
-    assert pairs > 150 and heads > 0.6 * pairs, (pairs, heads, still_full)
+    assert pairs > (120 if boxes else 150) and heads > 0.6 * pairs, (pairs, heads, still_full)
+    assert sampled_too > 60 or not boxes, sampled_too
     assert (into_layer + layer_fused > 0.2 * heads and layer_fused > 0.05 * heads) if blend else into_layer == layer_fused == 0, (into_layer, layer_fused, heads)
 
 
