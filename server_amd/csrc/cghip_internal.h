@@ -134,6 +134,7 @@ struct segment {
     int      one_temp = 0;         /* full, but RGBA2 is never touched, loaded or stored: 1; and no op with a blend mode
                                       (a MIX transition outside blend-mode layers): 2 */
     bool     mix_pairs = false;    /* holds fused MIX pairs (BB_MIX_HEAD) */
+    bool     yuv_lut = false;      /* has aligned draws of 8-bit planar / uyvy sources (KSpill::yuv_lut) */
     int      ext = 0;              /* fast: 1 a draw takes a sampled fetch body (FB_RECT8 ...), 2 a fused blend-mode layer */
     int      mono = -1;            /* fast, not full, ext 0: the one fetch body all its draws take (KSpill::mono), else -1 */
     uint32_t load_mask = 0, store_mask = 1; /* KSpill masks */

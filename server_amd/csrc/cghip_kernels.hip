@@ -1558,6 +1558,65 @@ DEV void convert_chroma(const Row3 t, const Row3 u, int sy, float o[4])
         o[i] = SB == 8 ? a[i] * (1.0f / 255.0f) : a[i];
 }
 
+/* ---- 8-bit planes: the YCbCr matrix's per-plane terms from tables in LDS ------------------------------------------
+ * A filtered 8-bit sample is an integer code 0..255 (the sampler's 8-bit-weight lerps round to codes), and the first
+ * half of ycbcra_to_rgba() is a function of ONE code each: 1.164 * (Y*255 - 16), and the four products k * (C*255 - 128).
+ * Every workgroup fills the 256 entries of each with the very expressions of ycbcra_to_rgba() (one code per thread,
+ * the unfused multiplies and subtractions of this build: bit-identical by construction) and the fetch bodies look them
+ * up: 13 vector instructions and 3 LDS reads per pixel instead of 27 instructions. 9 KB per workgroup. Only in the
+ * bit-exact build for 8-bit frames; the 4-pixels-per-lane kernels' aligned bodies (planar, uyvy). */
+#ifndef CGHIP_YUV_LUT
+#define CGHIP_YUV_LUT (CGHIP_FRAME_BITS == 8)
+#endif
+struct __attribute__((aligned(8))) f2 {
+    float x, y;
+};
+struct YuvLut {
+    float yy[256];    /* 1.164 * (Y * 255 - 16) */
+    f2    cr[2][256]; /* [hd]: (k_rr * cr, k_gr * cr), cr = Cr * 255 - 128 */
+    f2    cb[2][256]; /* [hd]: (k_gb * cb, k_bb * cb) */
+};
+#if CGHIP_YUV_LUT
+__shared__ YuvLut g_yuv_lut;
+DEV void fill_yuv_lut() /* every thread of the workgroup, before the first return; ends with the barrier */
+{
+    for (int c = (int)threadIdx.x; c < 256; c += (int)blockDim.x) {
+        const float v = (float)c * (1.0f / 255.0f); /* what convert_chroma() / fetch_planar() made of a code */
+        g_yuv_lut.yy[c] = 1.164f * (v * 255.0f - 16.0f);
+        const float ch = v * 255.0f - 128.0f;
+        g_yuv_lut.cr[0][c] = f2{1.596f * ch, 0.813f * ch};
+        g_yuv_lut.cr[1][c] = f2{1.793f * ch, 0.534f * ch};
+        g_yuv_lut.cb[0][c] = f2{0.391f * ch, 2.018f * ch};
+        g_yuv_lut.cb[1][c] = f2{0.213f * ch, 2.115f * ch};
+    }
+    __syncthreads();
+}
+#endif
+/* convert_row<8, HALF> / convert_chroma<8, HX, HY> with the codes left as integers */
+template <int HALF>
+DEV void codes_row8(const Row3 r, int o[4])
+{
+    if (!HALF) {
+        o[0] = (int)(r.a & 0xff), o[1] = (int)((r.a >> 8) & 0xff), o[2] = (int)((r.a >> 16) & 0xff), o[3] = (int)(r.a >> 24);
+    } else {
+        const int t0 = r.a & 0xff, t1 = (r.a >> 8) & 0xff, tl = (int)r.b, tr = (int)r.c;
+        o[0] = lerp8i(tl, t0, 192), o[1] = lerp8i(t0, t1, 64), o[2] = lerp8i(t0, t1, 192), o[3] = lerp8i(t1, tr, 64);
+    }
+}
+template <int HX, int HY>
+DEV void codes_chroma8(const Row3 t, const Row3 u, int sy, int o[4])
+{
+    codes_row8<HX>(t, o);
+    if (HY) {
+        const bool odd = sy & 1;
+        int        b[4];
+        codes_row8<HX>(u, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = lerp8i(o[i], b[i], odd ? 64 : 192);
+    }
+}
+
 /* source colours of four pixels from ycbcr / ycbcra planes (shader.frag:441-467,500-512) */
 template <int SB, int HX, int HY>
 DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
@@ -1583,6 +1642,42 @@ DEV void fetch_planar(const HotOp& op, int sx, int sy, bool red_only, f4 col[4])
         al = load_row<SB, 0>(op.ptr3, op.w3, sy, sx);
 
     const float sc = SB == 8 ? 1.0f / 255.0f : 1.0f;
+#if CGHIP_YUV_LUT
+    if constexpr (SB == 8) {
+        float Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (alpha) {
+            convert_row<8, 0>(al, Al);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                Al[i] *= sc;
+        }
+        const int hd = (op.flags & KF_IS_HD) ? 1 : 0;
+        int       Yc[4], Crc[4];
+        float     yy[4];
+        f2        a[4];
+        codes_row8<0>(y, Yc);
+        codes_chroma8<HX, HY>(cr0, cr1, sy, Crc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yy[i]    = g_yuv_lut.yy[Yc[i]];
+            a[i]     = g_yuv_lut.cr[hd][Crc[i]];
+            col[i].z = divc<RXF>((yy[i] + a[i].x), 255.0f, 1.0f / 255.0f);
+            col[i].w = Al[i];
+            col[i].x = col[i].y = 0.0f;
+        }
+        if (!red_only) {
+            int Cbc[4];
+            codes_chroma8<HX, HY>(cb0, cb1, sy, Cbc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f2 b = g_yuv_lut.cb[hd][Cbc[i]];
+                col[i].y   = divc<RXF>((yy[i] - a[i].y - b.x), 255.0f, 1.0f / 255.0f);
+                col[i].x   = divc<RXF>((yy[i] + b.y), 255.0f, 1.0f / 255.0f);
+            }
+        }
+        return;
+    }
+#endif
     float       Y[4], Cr[4], Al[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     convert_row<SB, 0>(y, Y);
     convert_chroma<SB, HX, HY>(cr0, cr1, sy, Cr);
@@ -1629,6 +1724,25 @@ DEV void fetch_uyvy8(const HotOp& op, int sx, int sy, f4 col[4])
     const u32x2    g   = load_at<u32x2>(row, (uint32_t)k * 4u);
     const uint32_t gl  = load_at<uint32_t>(row, (uint32_t)imax(k - 1, 0) * 4u);
     const uint32_t gr  = load_at<uint32_t>(row, (uint32_t)imin(k + 2, op.w1 - 1) * 4u);
+#if CGHIP_YUV_LUT
+    {
+        const int Yc[4] = {(int)((g.x >> 8) & 0xff), (int)(g.x >> 24), (int)((g.y >> 8) & 0xff), (int)(g.y >> 24)};
+        int       Cbc[4], Crc[4];
+        codes_row8<1>(Row3{(g.x & 0xff) | ((g.y & 0xff) << 8), gl & 0xff, gr & 0xff}, Cbc);
+        codes_row8<1>(Row3{((g.x >> 16) & 0xff) | (((g.y >> 16) & 0xff) << 8), (gl >> 16) & 0xff, (gr >> 16) & 0xff}, Crc);
+        const int hd = (op.flags & KF_IS_HD) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { /* ycbcra_to_rgba() from the tables, as in fetch_planar */
+            const float yy = g_yuv_lut.yy[Yc[i]];
+            const f2    a = g_yuv_lut.cr[hd][Crc[i]], b = g_yuv_lut.cb[hd][Cbc[i]];
+            col[i].z = divc<RXF>((yy + a.x), 255.0f, 1.0f / 255.0f);
+            col[i].y = divc<RXF>((yy - a.y - b.x), 255.0f, 1.0f / 255.0f);
+            col[i].x = divc<RXF>((yy + b.y), 255.0f, 1.0f / 255.0f);
+            col[i].w = 1.0f;
+        }
+        return;
+    }
+#endif
     const float    sc  = 1.0f / 255.0f;
     float          Y[4] = {(float)((g.x >> 8) & 0xff), (float)(g.x >> 24), (float)((g.y >> 8) & 0xff), (float)(g.y >> 24)};
     float          Cb[4], Cr[4];
@@ -2358,6 +2472,11 @@ DEV void composite_fast_body(const KOp* __restrict__ ops, int nops, void* out, i
     constexpr int  P       = 4;
     constexpr bool SAMPLED = EXT >= 1;
     constexpr bool FUSED   = FULL ? EXT >= 1 : EXT >= 2; /* the kernels with temporaries call the blend modes anyway */
+#if CGHIP_YUV_LUT
+    if constexpr (BITS == 8 && (MONO < 0 || (MONO >= FB_PLANAR8 && MONO < FB_PLANAR8 + 4) || MONO == FB_UYVY8))
+        if (sp.yuv_lut) /* a kernel argument: the whole workgroup or none. Before any return: it ends with a barrier */
+            fill_yuv_lut();
+#endif
     const int      lane = threadIdx.x & 63;
     const int      wave = threadIdx.x >> 6;
     unsigned       bx, by;

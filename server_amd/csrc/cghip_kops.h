@@ -135,6 +135,8 @@ struct KSpill {
     int32_t  fused; /* the launch holds a fused blend-mode layer (KOp::fused): picks the general kernel's instance */
     int32_t  mono;  /* lean 4-pixels-per-lane launches: the KFetchBody every draw of the launch takes, or -1 */
     int32_t  mix_pairs; /* the launch holds BB_MIX_HEAD ops: the lean kernel's instance that knows them */
+    int32_t  yuv_lut;  /* 8-bit build: the launch has aligned draws of 8-bit planar / uyvy sources, whose YCbCr terms come from
+                          tables every workgroup builds in LDS first (cghip_kernels.hip: YuvLut); 0: no tables, no barrier */
     int32_t  host_out; /* the frame buffer is pinned host memory (direct readback): plain stores, which the L2 merges
                           into whole lines before they cross PCIe; frames that stay in HBM leave through non-temporal
                           stores (written once, read by nobody on the GPU) */

@@ -865,6 +865,11 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         sg.mix_pairs = false;
         for (int i = sg.first; i < sg.first + sg.count; ++i)
             sg.mix_pairs = sg.mix_pairs || (ops[(size_t)i].kind == KOP_DRAW_PLANES && ops[(size_t)i].blend_body == BB_MIX_HEAD);
+        sg.yuv_lut = false;
+        for (int i = sg.first; i < sg.first + sg.count && sg.fast; ++i) {
+            const KOp& o = ops[(size_t)i];
+            sg.yuv_lut = sg.yuv_lut || (o.kind == KOP_DRAW_PLANES && ((o.fetch_body >= FB_PLANAR8 && o.fetch_body < FB_PLANAR8 + 4) || o.fetch_body == FB_UYVY8));
+        }
         sg.mono = -1; /* one source format throughout: the kernel instance compiled for that fetch body alone */
         if (sg.fast && sg.ext == 0) { /* launches with temporaries: the format of the draws that fetch from planes */
             int body = -2;

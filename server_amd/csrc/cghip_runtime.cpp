@@ -744,6 +744,7 @@ int cghip_mixer_render_async(cghip_mixer* mixer, const cghip_format* format, con
         sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp;
         sp.mono = sg.mono;
         sp.mix_pairs = sg.mix_pairs ? 1 : 0;
+        sp.yuv_lut = sg.yuv_lut ? 1 : 0;
         sp.host_out = direct ? 1 : 0;
         T_HIP(cghip_launch_composite((const KOp*)t->d_ops + sg.first, sg.count, direct ? t->h_out : t->d_out, format->width, format->height,
                                      format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 + sg.ext : 0, &sp,
@@ -888,6 +889,7 @@ int cghip_mixer_render_noalloc(cghip_mixer* mixer, const cghip_format* format, c
         sp.col_shift = sg.col_shift, sp.dense = sg.dense ? 1 : 0, sp.fused = sg.fused ? 1 : 0, sp.one_temp = sg.one_temp;
         sp.mono = sg.mono;
         sp.mix_pairs = sg.mix_pairs ? 1 : 0;
+        sp.yuv_lut = sg.yuv_lut ? 1 : 0;
         sp.host_out = 0; /* the caller's device memory */
         NA_HIP(cghip_launch_composite((const KOp*)base + sg.first, sg.count, device_out, format->width, format->height,
                                       format->bits, format->field_mode, sg.full ? 1 : 0, sg.fast ? 1 + sg.ext : 0, &sp,
