@@ -1592,6 +1592,23 @@ DEV void fill_yuv_lut() /* every thread of the workgroup, before the first retur
     __syncthreads();
 }
 #endif
+/* ycbcra_to_rgba(Y / 255, Cb / 255, Cr / 255, A, hd) for integer codes, from the tables where the build has them */
+DEV f4 ycbcr_codes_to_rgba(int Y, int Cb, int Cr, float A, int hd)
+{
+#if CGHIP_YUV_LUT
+    const float yy = g_yuv_lut.yy[Y];
+    const f2    a = g_yuv_lut.cr[hd][Cr], b = g_yuv_lut.cb[hd][Cb];
+    f4          c;
+    c.z = divc<RXF>((yy + a.x), 255.0f, 1.0f / 255.0f);
+    c.y = divc<RXF>((yy - a.y - b.x), 255.0f, 1.0f / 255.0f);
+    c.x = divc<RXF>((yy + b.y), 255.0f, 1.0f / 255.0f);
+    c.w = A;
+    return c;
+#else
+    const float sc = 1.0f / 255.0f;
+    return ycbcra_to_rgba((float)Y * sc, (float)Cb * sc, (float)Cr * sc, A, hd != 0);
+#endif
+}
 /* convert_row<8, HALF> / convert_chroma<8, HX, HY> with the codes left as integers */
 template <int HALF>
 DEV void codes_row8(const Row3 r, int o[4])
@@ -2127,11 +2144,12 @@ DEV ColTaps col_taps(int iu, int w)
     wx           = x0 > w - 2 ? 256 : wx;
     return ColTaps{(uint32_t)iclamp(x0, 0, w - 2), wx};
 }
-DEV float lerp_pairs8(uint32_t top, uint32_t bot, int wx, int wy) /* two 2-texel loads of a 1-channel plane */
+DEV int lerp_pairs8i(uint32_t top, uint32_t bot, int wx, int wy) /* two 2-texel loads of a 1-channel plane: the filtered code */
 {
     const int a = lerp8s((int)(top & 0xff), (int)(top >> 8), wx), b = lerp8s((int)(bot & 0xff), (int)(bot >> 8), wx);
-    return (float)lerp8s(a, b, wy);
+    return lerp8s(a, b, wy);
 }
+DEV float lerp_pairs8(uint32_t top, uint32_t bot, int wx, int wy) { return (float)lerp_pairs8i(top, bot, wx, wy); }
 /* Two lerp8s at once on words of the form 0x00XX00XX (one 8-bit sample per 16-bit half) that share a weight - Cb and Cr of
  * a pixel always do: a + (((b - a) * w + 128) >> 8) = (a * (256 - w) + b * w + 128) >> 8, the sum is at most 255 * 256 +
  * 128 < 2^16, so the halves never carry into each other and each is exactly lerp8s of its samples (weight 256 of the
@@ -2141,13 +2159,13 @@ DEV uint32_t lerp8x2_raw(uint32_t a, uint32_t b, uint32_t w, uint32_t iw)
     return __umul24(a, iw) + __umul24(b, w) + 0x00800080u;
 }
 /* the Cb and Cr samples of a pixel from their four tap pairs (two texels per 16-bit load, zero-extended) */
-DEV void lerp_chroma8(uint32_t cbt, uint32_t cbb, uint32_t crt, uint32_t crb, int wx, int wy, float& Cb, float& Cr)
+DEV void lerp_chroma8(uint32_t cbt, uint32_t cbb, uint32_t crt, uint32_t crb, int wx, int wy, int& Cb, int& Cr)
 {
     const uint32_t w = (uint32_t)wx, iw = 256u - w;
     const uint32_t top = (lerp8x2_raw(__builtin_amdgcn_perm(crt, cbt, 0x0c040c00u), __builtin_amdgcn_perm(crt, cbt, 0x0c050c01u), w, iw) >> 8) & 0x00FF00FFu;
     const uint32_t bot = (lerp8x2_raw(__builtin_amdgcn_perm(crb, cbb, 0x0c040c00u), __builtin_amdgcn_perm(crb, cbb, 0x0c050c01u), w, iw) >> 8) & 0x00FF00FFu;
     const uint32_t v   = lerp8x2_raw(top, bot, (uint32_t)wy, 256u - (uint32_t)wy);
-    Cb = (float)((v >> 8) & 0xffu), Cr = (float)(v >> 24);
+    Cb = (int)((v >> 8) & 0xffu), Cr = (int)(v >> 24);
 }
 template <bool PACKED, bool UNIT>
 DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, int y, f4 col[4], uint32_t& cover)
@@ -2210,10 +2228,10 @@ DEV void fetch_rect8(const KOp& op, const HotG& g, int ax0, int ax1, int px0, in
         });
         static_for<0, 4>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            const float   Y = lerp_pairs8(yt[i], yb[i], c0[i].wx, ry.wy) * sc;
-            float         Cb, Cr;
+            const int     Y = lerp_pairs8i(yt[i], yb[i], c0[i].wx, ry.wy);
+            int           Cb, Cr;
             lerp_chroma8(bt[i], bb[i], rt[i], rbm[i], c1[i].wx, rb.wy, Cb, Cr);
-            col[i] = ycbcra_to_rgba(Y, Cb * sc, Cr * sc, 1.0f, hd);
+            col[i] = ycbcr_codes_to_rgba(Y, Cb, Cr, 1.0f, hd ? 1 : 0);
         });
         if (alpha) { /* wave-uniform, and rare (ycbcra): a second round trip of its own, so that the eight registers of
                         its taps are not held (as zeros) through the three planes every ycbcr box has */
@@ -2243,7 +2261,6 @@ DEV void fetch_rect_uyvy8(const KOp& op, const HotG& g, int ax0, int ax1, int px
     const float  sw0 = UNIT ? (g.fw0 / g.fw0) * 256.0f : g.fw0 * 256.0f, sw1 = UNIT ? (g.fw1 / g.fw0) * 256.0f : g.fw1 * 256.0f;
     const int    iv0 = __builtin_amdgcn_readfirstlane(coord(t, sh0)), iv1 = __builtin_amdgcn_readfirstlane(coord(t, sh1));
     const double a01 = T.a[0][1], a00 = T.a[0][0];
-    const float  sc  = 1.0f / 255.0f;
     const RowTaps ry = row_taps(g.ptr0, iv0, g.w0, g.h0, 2u), rc = row_taps(g.ptr1, iv1, g.w1, g.h1, 4u);
     const bool    hd = g.flags & KF_IS_HD;
     ColTaps       c0[4], c1[4];
@@ -2264,14 +2281,13 @@ DEV void fetch_rect_uyvy8(const KOp& op, const HotG& g, int ax0, int ax1, int px
     static_for<0, 4>([&](auto I) {
         constexpr int i = decltype(I)::value;
         const int     wx0 = c0[i].wx, wx1 = c1[i].wx;
-        const float   Y = (float)lerp8s(lerp8s((yt[i] >> 8) & 0xff, yt[i] >> 24, wx0), lerp8s((yb[i] >> 8) & 0xff, yb[i] >> 24, wx0), ry.wy);
+        const int     Y = lerp8s(lerp8s((yt[i] >> 8) & 0xff, yt[i] >> 24, wx0), lerp8s((yb[i] >> 8) & 0xff, yb[i] >> 24, wx0), ry.wy);
         /* U and V sit in bytes 0 and 2 of a texel of the RGBA8 view: both lerped at once (lerp8x2_raw) */
         const uint32_t w1 = (uint32_t)wx1, iw1 = 256u - w1, m = 0x00FF00FFu;
         const uint32_t top = (lerp8x2_raw(ct[i].x & m, ct[i].y & m, w1, iw1) >> 8) & m;
         const uint32_t bot = (lerp8x2_raw(cb[i].x & m, cb[i].y & m, w1, iw1) >> 8) & m;
         const uint32_t uv  = lerp8x2_raw(top, bot, (uint32_t)rc.wy, 256u - (uint32_t)rc.wy);
-        const float    U = (float)((uv >> 8) & 0xffu), V = (float)(uv >> 24);
-        col[i] = ycbcra_to_rgba(Y * sc, U * sc, V * sc, 1.0f, hd);
+        col[i] = ycbcr_codes_to_rgba(Y, (int)((uv >> 8) & 0xffu), (int)(uv >> 24), 1.0f, hd ? 1 : 0);
     });
 }
 

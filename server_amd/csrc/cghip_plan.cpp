@@ -868,7 +868,9 @@ static void split_into_segments(const cghip_format& fmt, frame_plan* out)
         sg.yuv_lut = false;
         for (int i = sg.first; i < sg.first + sg.count && sg.fast; ++i) {
             const KOp& o = ops[(size_t)i];
-            sg.yuv_lut = sg.yuv_lut || (o.kind == KOP_DRAW_PLANES && ((o.fetch_body >= FB_PLANAR8 && o.fetch_body < FB_PLANAR8 + 4) || o.fetch_body == FB_UYVY8));
+            sg.yuv_lut = sg.yuv_lut || (o.kind == KOP_DRAW_PLANES && ((o.fetch_body >= FB_PLANAR8 && o.fetch_body < FB_PLANAR8 + 4) || o.fetch_body == FB_UYVY8 ||
+                                                                      o.fetch_body == FB_RECT8 || o.fetch_body == FB_RECT8 + 2 || /* sampled boxes of planes */
+                                                                      o.fetch_body == FB_RECT_UYVY8 || o.fetch_body == FB_RECT_UYVY8 + 1));
         }
         sg.mono = -1; /* one source format throughout: the kernel instance compiled for that fetch body alone */
         if (sg.fast && sg.ext == 0) { /* launches with temporaries: the format of the draws that fetch from planes */
